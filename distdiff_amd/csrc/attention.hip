@@ -1,0 +1,532 @@
+// K5 / K11 — flash attention forward and backward (dQ, dK, dV) on bf16 MFMA 16x16x32, gfx950.
+// Replaces F.scaled_dot_product_attention inside diffusers' Attention processor for UNet self-attention
+// (N = 4096/1024/256/64, d = 40/80/160), cross-attention (77 keys; backward needs dQ only) and the VAE
+// mid-block single-head attention (d = 512) — reference call sites generate_data.py:112, :701 — and
+// its autograd backward (:721, :761).
+//
+// One design for all three kernels: the "owner" index (queries for fwd/dQ, keys for dK/dV) lives on the
+// MFMA column (lane & 15) so every per-row statistic (running max, sum, LSE, delta) is lane-local; the
+// streamed side goes through LDS as plain row-major [row][d] tiles (coalesced 16-byte staging) and is
+// consumed either by rows (ds_read_b128: QK^T, dO V^T) or by columns (ds_read_b64_tr_b16: P V, dS K, ...).
+// Scores are produced transposed (S^T = K Q^T), so the fp32 accumulator registers of S^T are, after
+// exp/bf16 packing, directly the B operand of the next MFMA (no LDS round trip, no shuffles): the k-order
+// inside a 32-deep step is the permutation key = 32c + 16*(j>>2) + 4*(lane>>4) + (j&3), which is exactly the
+// 4-row block order ds_read_b64_tr_b16 delivers. Row stride of the LDS tiles is 2*DPK+32 bytes:
+// bank-conflict free for both read kinds (tools/lds_conflicts.py).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 lds_row_frag(const unsigned char* base, int row, int S, int slot) {
+  return *(const bf16x8*)(base + row * S + slot * 16);
+}
+// 8 k-values (permuted order, see header) of column `col16 + (lane&15)`: rows r0 + 4*(lane>>4) + {0..3} and +16
+__device__ __forceinline__ bf16x8 lds_col_frag(const unsigned char* base, int r0, int S, int col16, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const unsigned char* a = base + (r0 + 4 * g + (i >> 2)) * S + (col16 * 16 + 4 * (i & 3)) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 16 * S));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  uint4 u;
+  u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+// stage ROWS x DPK bf16 (zero padded beyond D columns / nvalid rows) into LDS with row stride S bytes
+template <int ROWS, int DPK>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, int S, const bf16_t* g, int ld, int nvalid, int D, int tid) {
+  constexpr int VPR = DPK / 8;
+  for (int idx = tid; idx < ROWS * VPR; idx += 256) {
+    const int r = idx / VPR, v = idx % VPR;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (r < nvalid && v * 8 < D) val = *(const uint4*)(g + (size_t)r * ld + v * 8);
+    *(uint4*)(lds + r * S + v * 16) = val;
+  }
+}
+template <int DPK>
+__device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* g, bool valid, int D, int lane) {
+  const int gq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < DPK / 32; ++ks) {
+    const int d0 = ks * 32 + gq * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid && d0 < D) v = *(const uint4*)(g + d0);
+    f[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------
+// forward.  grid (ceil(Nq / QB), H, B), 256 threads. DSPLIT=1: each wave owns QT 16-query tiles;
+// DSPLIT=4: the 4 waves share one set of QT tiles and each accumulates a quarter of the head dim (d=512).
+// ------------------------------------------------------------------------------------------------
+template <int D, int QT, int KT, int DSPLIT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  constexpr int DPK = (D + 31) / 32 * 32;
+  constexpr int KS = DPK / 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr int DTW = DVT / DSPLIT;          // dv tiles per wave
+  constexpr int S = DPK * 2 + 32;
+  constexpr int NKT = KT / 16, NC = KT / 32;
+  constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + KT * S;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * QB + (DSPLIT == 1 ? wave * QT * 16 : 0);
+  const int dt0 = (DSPLIT == 1) ? 0 : wave * DTW;
+
+  bf16x8 qf[QT][KS];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + i16;
+    const bool valid = qrow[qt] < p.Nq;
+    load_row_frags<DPK>(qf[qt], p.q + ((size_t)b * p.Nq + (valid ? qrow[qt] : 0)) * p.ldq + h * D, valid, D, lane);
+  }
+  f32x4 o[QT][DTW];
+  float mrun[QT], lsum[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = -INFINITY; lsum[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+  const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+
+  for (int k0 = 0; k0 < p.Nk; k0 += KT) {
+    __syncthreads();
+    stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
+    stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    __syncthreads();
+    f32x4 st[QT][NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
+      }
+    }
+    bf16x8 pf[QT][NC];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + kt * 16 + 4 * g + r;
+          const float t = key < p.Nk ? st[qt][kt][r] * sl2 : -INFINITY;
+          st[qt][kt][r] = t;
+          mx = fmaxf(mx, t);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = exp2f(mrun[qt] - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(st[qt][kt][r] - mnew);
+          st[qt][kt][r] = e;
+          ps += e;
+        }
+      lsum[qt] = lsum[qt] * alpha + ps;
+      mrun[qt] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < DTW; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) pf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 vf = lds_col_frag(Vs, 32 * c, S, dt0 + dt, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], o[qt][dt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = lsum[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[qt] >= p.Nq) continue;
+    const float inv = 1.f / l;
+    bf16_t* op = p.o + ((size_t)b * p.Nq + qrow[qt]) * p.ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) {
+      const int dv = (dt0 + dt) * 16 + 4 * g;
+      if (dv < D) {
+        uint2 u;
+        u.x = pack2bf(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+        u.y = pack2bf(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+        *(uint2*)(op + dv) = u;
+      }
+    }
+    if (p.lse && g == 0 && (DSPLIT == 1 || wave == 0))
+      p.lse[((size_t)b * p.H + h) * p.Nq + qrow[qt]] = (mrun[qt] + log2f(l)) * 0.6931471805599453f;
+  }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  const int D = p.D;
+  const size_t total = (size_t)p.B * p.H * p.Nq;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int q = (int)(idx % p.Nq);
+    const int h = (int)((idx / p.Nq) % p.H);
+    const int b = (int)(idx / ((size_t)p.Nq * p.H));
+    const bf16_t* op = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+    const bf16_t* dp = p.d_o + ((size_t)b * p.Nq + q) * p.lddo + h * D;
+    float s = 0.f;
+    for (int d = 0; d < D; d += 8) {
+      float a[8], c[8];
+      unpack8(*(const uint4*)(op + d), a);
+      unpack8(*(const uint4*)(dp + d), c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+    }
+    p.delta[idx] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: same streaming structure as the forward (keys/values through LDS).
+//   dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T dS^T
+// ------------------------------------------------------------------------------------------------
+template <int D, int QT, int KT, int DSPLIT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int DPK = (D + 31) / 32 * 32;
+  constexpr int KS = DPK / 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr int DTW = DVT / DSPLIT;
+  constexpr int S = DPK * 2 + 32;
+  constexpr int NKT = KT / 16, NC = KT / 32;
+  constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + KT * S;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * QB + (DSPLIT == 1 ? wave * QT * 16 : 0);
+  const int dt0 = (DSPLIT == 1) ? 0 : wave * DTW;
+
+  bf16x8 qf[QT][KS], dof[QT][KS];
+  int qrow[QT];
+  float lse2[QT], delta[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + i16;
+    const bool valid = qrow[qt] < p.Nq;
+    const size_t r = (size_t)b * p.Nq + (valid ? qrow[qt] : 0);
+    load_row_frags<DPK>(qf[qt], p.q + r * p.ldq + h * D, valid, D, lane);
+    load_row_frags<DPK>(dof[qt], p.d_o + r * p.lddo + h * D, valid, D, lane);
+    const size_t si = ((size_t)b * p.H + h) * p.Nq + (valid ? qrow[qt] : 0);
+    lse2[qt] = valid ? p.lse[si] * LOG2E : 0.f;
+    delta[qt] = valid ? p.delta[si] : 0.f;
+  }
+  f32x4 dq[QT][DTW];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * LOG2E;
+  const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+  const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+
+  for (int k0 = 0; k0 < p.Nk; k0 += KT) {
+    __syncthreads();
+    stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
+    stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    __syncthreads();
+    bf16x8 dsf[QT][NC];
+    {
+      f32x4 st[QT][NKT], dpt[QT][NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) { st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
+          const bf16x8 vf = lds_row_frag(Vs, kt * 16 + i16, S, g + 4 * ks);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
+            dpt[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ks], dpt[qt][kt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kt * 16 + 4 * g + r;
+            const float pr = key < p.Nk ? exp2f(st[qt][kt][r] * sl2 - lse2[qt]) : 0.f;
+            st[qt][kt][r] = pr * (dpt[qt][kt][r] - delta[qt]);
+          }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dsf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 kcf = lds_col_frag(Ks, 32 * c, S, dt0 + dt, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf, dsf[qt][c], dq[qt][dt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    if (qrow[qt] >= p.Nq) continue;
+    bf16_t* op = p.dq + ((size_t)b * p.Nq + qrow[qt]) * p.lddq + h * D;
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) {
+      const int dv = (dt0 + dt) * 16 + 4 * g;
+      if (dv < D) {
+        uint2 u;
+        u.x = pack2bf(dq[qt][dt][0] * p.scale, dq[qt][dt][1] * p.scale);
+        u.y = pack2bf(dq[qt][dt][2] * p.scale, dq[qt][dt][3] * p.scale);
+        *(uint2*)(op + dv) = u;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV: keys own the lanes, queries (Q, dO, LSE, delta) stream through LDS.
+//   S = Q K^T ; P = exp(S*scale - LSE) ; dP = dO V^T ; dS = P o (dP - delta)
+//   dV^T += dO^T P ; dK^T += Q^T dS
+// ------------------------------------------------------------------------------------------------
+template <int D, int KTW, int QTL, int DSPLIT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int DPK = (D + 31) / 32 * 32;
+  constexpr int KS = DPK / 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr int DTW = DVT / DSPLIT;
+  constexpr int S = DPK * 2 + 32;
+  constexpr int NQT = QTL / 16, NC = QTL / 32;
+  constexpr int KB = (DSPLIT == 1 ? 4 : 1) * KTW * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem;
+  unsigned char* Os = smem + QTL * S;
+  float* ls = (float*)(smem + 2 * QTL * S);   // [QTL] lse*log2e, then [QTL] delta
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kbase = blockIdx.x * KB + (DSPLIT == 1 ? wave * KTW * 16 : 0);
+  const int dt0 = (DSPLIT == 1) ? 0 : wave * DTW;
+
+  bf16x8 kf[KTW][KS], vf[KTW][KS];
+  int krow[KTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    krow[kt] = kbase + kt * 16 + i16;
+    const bool valid = krow[kt] < p.Nk;
+    const size_t r = (size_t)b * p.Nk + (valid ? krow[kt] : 0);
+    load_row_frags<DPK>(kf[kt], p.k + r * p.ldk + h * D, valid, D, lane);
+    load_row_frags<DPK>(vf[kt], p.v + r * p.ldv + h * D, valid, D, lane);
+  }
+  f32x4 dk[KTW][DTW], dv[KTW][DTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) { dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float sl2 = p.scale * LOG2E;
+  const bf16_t* qg = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+  const bf16_t* og = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+  const float* lseg = p.lse + ((size_t)b * p.H + h) * p.Nq;
+  const float* delg = p.delta + ((size_t)b * p.H + h) * p.Nq;
+
+  for (int q0 = 0; q0 < p.Nq; q0 += QTL) {
+    __syncthreads();
+    stage_tile<QTL, DPK>(Qs, S, qg + (size_t)q0 * p.ldq, p.ldq, p.Nq - q0, D, tid);
+    stage_tile<QTL, DPK>(Os, S, og + (size_t)q0 * p.lddo, p.lddo, p.Nq - q0, D, tid);
+    if (tid < QTL) {
+      const bool v = q0 + tid < p.Nq;
+      ls[tid] = v ? lseg[q0 + tid] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
+      ls[QTL + tid] = v ? delg[q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    bf16x8 pf[KTW][NC], dsf[KTW][NC];
+    {
+      f32x4 s[KTW][NQT], dp[KTW][NQT];
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) { s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qfr = lds_row_frag(Qs, qt * 16 + i16, S, g + 4 * ks);
+          const bf16x8 ofr = lds_row_frag(Os, qt * 16 + i16, S, g + 4 * ks);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], s[kt][qt], 0, 0, 0);
+            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kt][ks], dp[kt][qt], 0, 0, 0);
+          }
+        }
+      }
+      // s[kt][qt][r] = S[q = q0 + qt*16 + 4g + r][key = krow[kt]]
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        float l2[4], de[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { l2[r] = ls[qt * 16 + 4 * g + r]; de[r] = ls[QTL + qt * 16 + 4 * g + r]; }
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = exp2f(s[kt][qt][r] * sl2 - l2[r]);
+            s[kt][qt][r] = pr;
+            dp[kt][qt][r] = pr * (dp[kt][qt][r] - de[r]);
+          }
+      }
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          pf[kt][c] = pack_frag(s[kt][2 * c], s[kt][2 * c + 1]);
+          dsf[kt][c] = pack_frag(dp[kt][2 * c], dp[kt][2 * c + 1]);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 ocf = lds_col_frag(Os, 32 * c, S, dt0 + dt, lane);
+        const bf16x8 qcf = lds_col_frag(Qs, 32 * c, S, dt0 + dt, lane);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) {
+          dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ocf, pf[kt][c], dv[kt][dt], 0, 0, 0);
+          dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcf, dsf[kt][c], dk[kt][dt], 0, 0, 0);
+        }
+      }
+  }
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    if (krow[kt] >= p.Nk) continue;
+    bf16_t* kp = p.dk + ((size_t)b * p.Nk + krow[kt]) * p.lddk + h * D;
+    bf16_t* vp = p.dv + ((size_t)b * p.Nk + krow[kt]) * p.lddv + h * D;
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) {
+      const int d = (dt0 + dt) * 16 + 4 * g;
+      if (d < D) {
+        uint2 u;
+        u.x = pack2bf(dk[kt][dt][0] * p.scale, dk[kt][dt][1] * p.scale);
+        u.y = pack2bf(dk[kt][dt][2] * p.scale, dk[kt][dt][3] * p.scale);
+        *(uint2*)(kp + d) = u;
+        u.x = pack2bf(dv[kt][dt][0], dv[kt][dt][1]);
+        u.y = pack2bf(dv[kt][dt][2], dv[kt][dt][3]);
+        *(uint2*)(vp + d) = u;
+      }
+    }
+  }
+}
+
+template <int D, int QT, int KT, int DSPLIT>
+hipError_t run_fwd(const AttnParams& p, hipStream_t s) {
+  constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
+  constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
+  constexpr size_t lds = 2 * KT * S;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<D, QT, KT, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+template <int D, int QT, int KT, int DSPLIT>
+hipError_t run_dq(const AttnParams& p, hipStream_t s) {
+  constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
+  constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
+  constexpr size_t lds = 2 * KT * S;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, QT, KT, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, QT, KT, DSPLIT>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+template <int D, int KTW, int QTL, int DSPLIT>
+hipError_t run_dkv(const AttnParams& p, hipStream_t s) {
+  constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
+  constexpr int KB = (DSPLIT == 1 ? 4 : 1) * KTW * 16;
+  constexpr size_t lds = 2 * QTL * S + 2 * QTL * sizeof(float);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT>), dim3((p.Nk + KB - 1) / KB, p.H, p.B), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+static bool attn_check(const AttnParams& p) {
+  return !(p.ldq & 7) && !(p.ldk & 7) && !(p.ldv & 7) && !(p.ldo & 3) && p.Nq > 0 && p.Nk > 0;
+}
+
+hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
+  if (!attn_check(p)) return hipErrorInvalidValue;
+  switch (p.D) {
+    case 32: return run_fwd<32, 2, 64, 1>(p, s);
+    case 40: return run_fwd<40, 2, 64, 1>(p, s);
+    case 64: return run_fwd<64, 2, 64, 1>(p, s);
+    case 80: return run_fwd<80, 2, 64, 1>(p, s);
+    case 160: return run_fwd<160, 2, 64, 1>(p, s);
+    case 512: return run_fwd<512, 1, 32, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t s) {
+  if (!attn_check(p) || (p.lddo & 7) || (p.lddq & 3) || !p.delta || !p.lse) return hipErrorInvalidValue;
+  {
+    const size_t total = (size_t)p.B * p.H * p.Nq;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, s, p);
+  }
+  hipError_t e;
+  switch (p.D) {
+    case 32: e = run_dq<32, 2, 64, 1>(p, s); break;
+    case 40: e = run_dq<40, 2, 64, 1>(p, s); break;
+    case 64: e = run_dq<64, 2, 64, 1>(p, s); break;
+    case 80: e = run_dq<80, 1, 64, 1>(p, s); break;
+    case 160: e = run_dq<160, 1, 64, 1>(p, s); break;
+    case 512: e = run_dq<512, 1, 32, 4>(p, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess || !p.dk) return e;
+  if ((p.lddk & 3) || (p.lddv & 3)) return hipErrorInvalidValue;
+  switch (p.D) {
+    case 32: return run_dkv<32, 2, 64, 1>(p, s);
+    case 40: return run_dkv<40, 2, 64, 1>(p, s);
+    case 64: return run_dkv<64, 2, 64, 1>(p, s);
+    case 80: return run_dkv<80, 1, 64, 1>(p, s);
+    case 160: return run_dkv<160, 1, 64, 1>(p, s);
+    case 512: return run_dkv<512, 1, 32, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -1,0 +1,398 @@
+// K1/K2/K8 — implicit-GEMM convolution / GEMM / linear on bf16 MFMA (v_mfma_f32_16x16x32_bf16), gfx950.
+//
+// Replaces the cuDNN/cuBLAS kernels PyTorch dispatches for diffusers' Conv2d / Linear inside
+// UNet2DConditionModel, AutoencoderKL.decode and timm resnet50 (reference call sites:
+// generate_data.py:112, :701, :705) and their input-gradients (torch.autograd.grad, :721/:761).
+//
+// Layout: activations NHWC bf16 (a [pixels, C] row-major matrix, arbitrary row stride so channel
+// concatenation is a view), weights pre-packed [N][K] with k = (tap, cin), cin fastest (cin % 8 == 0).
+// Tile: (WM*64) x (WN*64) x 64 per workgroup, one 64x64 sub-tile per wave (4x4 MFMA 16x16x32
+// tiles, fp32 accumulators), LDS double-buffered with 128-byte rows XOR-swizzled by (row & 7) so that
+// both the staging ds_write_b128 and the fragment ds_read_b128 are bank-conflict free
+// (tools/lds_conflicts.py), register-staged global->LDS prefetch of the next K-step under the MFMAs.
+// The MFMA is issued "swapped" (A = weight rows, B = pixel rows) so each lane owns 4 consecutive
+// output channels of one pixel: epilogue loads/stores are 8-byte (bf16x4) / 16-byte (fp32x4) vectors.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct Epi {
+  // applies bias / GEGLU / residual / relu / mask and stores 4 consecutive output columns of row m.
+  static __device__ __forceinline__ void apply(const ConvGemmParams& p, const float* bias, int m, int nb, float* h,
+                                               float* g, int nb_gate) {
+    const int flags = p.flags;
+    int ncols;  // logical output columns
+    int ob;     // output column base
+    if (flags & CF_GEGLU) {
+      ncols = p.N >> 1;
+      ob = (nb >> 5) * 16 + (nb & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float hv = h[r] * p.alpha, gv = g[r] * p.alpha;
+        if (flags & CF_BIAS) {
+          if (nb + r < p.N) hv += bias[nb + r];
+          if (nb_gate + r < p.N) gv += bias[nb_gate + r];
+        }
+        if ((flags & CF_GEGLU_RAW) && nb + r < p.N) {
+          p.raw[(size_t)m * p.raw_ld + nb + r] = f2bf(hv);
+          p.raw[(size_t)m * p.raw_ld + nb_gate + r] = f2bf(gv);
+        }
+        h[r] = hv * gelu_f(gv);
+      }
+    } else {
+      ncols = p.N;
+      ob = nb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = h[r] * p.alpha;
+        if ((flags & CF_BIAS) && nb + r < p.N) v += bias[nb + r];
+        h[r] = v;
+      }
+    }
+    const bool full = (ob + 4 <= ncols);
+    if (flags & CF_RES) {
+      if (flags & CF_RES_F32) {
+        const float* rp = (const float*)p.res + (size_t)m * p.res_ld + ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < ncols) h[r] += rp[r];
+      } else {
+        const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld + ob;
+        if (full && !(p.res_ld & 3)) {
+          uint2 rv = *(const uint2*)rp;
+          h[0] += __uint_as_float(rv.x << 16); h[1] += __uint_as_float(rv.x & 0xffff0000u);
+          h[2] += __uint_as_float(rv.y << 16); h[3] += __uint_as_float(rv.y & 0xffff0000u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ob + r < ncols) h[r] += bf2f(rp[r]);
+        }
+      }
+    }
+    if (flags & CF_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+    }
+    if (flags & CF_MASK) {
+      const bf16_t* mp = p.mask + (size_t)m * p.mask_ld + ob;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ob + r < ncols && !(bf2f(mp[r]) > 0.f)) h[r] = 0.f;
+    }
+    if (flags & CF_OUT_F32) {
+      float* yp = (float*)p.y + (size_t)m * p.y_ld + ob;
+      if (full && !(p.y_ld & 3)) {
+        *(float4*)yp = make_float4(h[0], h[1], h[2], h[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < ncols) yp[r] = h[r];
+      }
+    } else {
+      bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld + ob;
+      if (full && !(p.y_ld & 3)) {
+        uint2 o; o.x = pack2bf(h[0], h[1]); o.y = pack2bf(h[2], h[3]);
+        *(uint2*)yp = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < ncols) yp[r] = f2bf(h[r]);
+      }
+    }
+  }
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvGemmParams p) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int NT = WM * WN * 64;
+  constexpr int RPT = NT / 8;   // tile rows covered by one staging pass (8 x 16-byte slots per 128-byte row)
+  constexpr int AV = BM / RPT;  // staging vectors per thread per K-step
+  constexpr int BV = BN / RPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- tile mapping: XCD-aware (blocks b, b+8, ... share an L2) with n-tiles fastest, so that the
+  // blocks of one XCD walk neighbouring pixel rows against the same weights.
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int nblk = ntm * ntn;
+  int logical;
+  {
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (logical / ntn) * BM;
+  const int n0 = (logical % ntn) * BN;
+
+  const int ksteps = p.K >> 6;
+  const int per = (ksteps + p.ksplit - 1) / p.ksplit;
+  const int kz = blockIdx.y;
+  const int k_begin = kz * per;
+  const int k_end = min(ksteps, k_begin + per);
+
+  // ---- staging assignment
+  const int j = tid & 7;
+  const int r0 = tid >> 3;
+  int pixb[AV], iy0[AV], ix0[AV];
+  {
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int m = m0 + r0 + RPT * i;
+      if (m < p.M) {
+        const int b = m / HoWo;
+        const int rem = m - b * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        pixb[i] = b * p.H * p.W;
+        iy0[i] = oy * p.stride;
+        ix0[i] = ox * p.stride;
+      } else {
+        pixb[i] = 0; iy0[i] = -1000000; ix0[i] = 0;
+      }
+    }
+  }
+  uint4 ra[AV], rb[BV];
+  const int shift = p.shift, parity = p.parity;
+
+  unsigned okmask = 0;
+  const int cin = p.cin, cin8 = p.cin >> 3;
+  const bool uniform_tap = (cin & 63) == 0;  // every 64-deep K-step lies inside one filter tap
+  auto load_tile = [&](int kt) {
+    okmask = 0;
+    int e, coff;
+    bool ev;
+    if (uniform_tap) {
+      const int tap = (kt * 64) / cin;            // wave-uniform: scalar ALU + s_load
+      coff = kt * 64 - tap * cin + j * 8;
+      e = p.taptab[tap];
+      ev = true;
+    } else {
+      const int k8 = kt * 8 + j;
+      const int tap = k8 / cin8;
+      ev = tap < p.ntaps;
+      coff = (k8 - tap * cin8) * 8;
+      e = p.taptab[ev ? tap : 0];
+    }
+    const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int ly = iy0[i] + dy, lx = ix0[i] + dx;
+      const int sy = ly >> shift, sx = lx >> shift;
+      bool ok = ev && ly >= 0 && lx >= 0 && sy < p.H && sx < p.W;
+      if (parity) ok = ok && (((ly | lx) & 1) == 0);
+      const unsigned off = ok ? (unsigned)(pixb[i] + sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)coff : 0u;
+      ra[i] = *(const uint4*)(p.x + off);  // unconditional load from a safe address; zero-select at LDS-store time
+      okmask |= ok ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + r0 + RPT * i;
+      const bool okn = n < p.N;
+      rb[i] = *(const uint4*)(p.w + (size_t)(okn ? n : 0) * p.K + (size_t)kt * 64 + j * 8);
+      okmask |= okn ? (1u << (16 + i)) : 0u;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* A = smem + buf * BUF_BYTES;
+    unsigned char* Bt = A + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int row = r0 + RPT * i;
+      const bool ok = (okmask >> i) & 1u;
+      uint4 v = ra[i];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+      *(uint4*)(A + row * 128 + ((j ^ (row & 7)) << 4)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int row = r0 + RPT * i;
+      const bool ok = (okmask >> (16 + i)) & 1u;
+      uint4 v = rb[i];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+      *(uint4*)(Bt + row * 128 + ((j ^ (row & 7)) << 4)) = v;
+    }
+  };
+
+  f32x4 acc[4][4];  // [jn][i]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const unsigned char* A = smem + buf * BUF_BYTES;
+    const unsigned char* Bt = A + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[4], wf[4];
+      const int slot = fq + 4 * ks;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        xf[i] = *(const bf16x8*)(A + row * 128 + ((slot ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int row = wn * 64 + jn * 16 + fr;
+        wf[jn] = *(const bf16x8*)(Bt + row * 128 + ((slot ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[i], acc[jn][i], 0, 0, 0);
+    }
+  };
+
+  if (k_begin < k_end) {
+    load_tile(k_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      const int cur = (kt - k_begin) & 1;
+      const bool more = (kt + 1 < k_end);
+      if (more) load_tile(kt + 1);
+      compute(cur);
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue. acc[jn][i][r]: n = n0 + wn*64 + jn*16 + fq*4 + r ; m = m0 + wm*64 + i*16 + fr
+  if (p.ksplit > 1) {
+    float* part = p.partial + (size_t)kz * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int nb = n0 + wn * 64 + jn * 16 + fq * 4;
+        float* pp = part + (size_t)m * p.N + nb;
+        if (nb + 4 <= p.N && !(p.N & 3)) {
+          *(float4*)pp = make_float4(acc[jn][i][0], acc[jn][i][1], acc[jn][i][2], acc[jn][i][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < p.N) pp[r] = acc[jn][i][r];
+        }
+      }
+    }
+    return;
+  }
+  const float* bias = p.bias;
+  if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+    if (p.flags & CF_GEGLU) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int nb = n0 + wn * 64 + (2 * t) * 16 + fq * 4;
+        if (nb >= p.N) continue;
+        float h[4], g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = acc[2 * t][i][r]; g[r] = acc[2 * t + 1][i][r]; }
+        Epi::apply(p, bias, m, nb, h, g, nb + 16);
+      }
+    } else {
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int nb = n0 + wn * 64 + jn * 16 + fq * 4;
+        if (nb >= p.N) continue;
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = acc[jn][i][r];
+        Epi::apply(p, bias, m, nb, h, h, 0);
+      }
+    }
+  }
+}
+
+// split-K reduction + epilogue: one thread per (row, 4 logical output columns)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvGemmParams p) {
+  const int geglu = (p.flags & CF_GEGLU) ? 1 : 0;
+  const int ncols = geglu ? (p.N >> 1) : p.N;
+  const int ngrp = (ncols + 3) >> 2;
+  const size_t total = (size_t)p.M * ngrp;
+  const float* bias = p.bias;
+  if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / ngrp);
+    const int ob = (int)(idx % ngrp) * 4;
+    int nb, nbg = 0;
+    if (geglu) { nb = (ob >> 4) * 32 + (ob & 15); nbg = nb + 16; } else nb = ob;
+    float h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    for (int z = 0; z < p.ksplit; ++z) {
+      const float* pp = p.partial + ((size_t)z * p.M + m) * p.N;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r < p.N) h[r] += pp[nb + r];
+        if (geglu && nbg + r < p.N) g[r] += pp[nbg + r];
+      }
+    }
+    Epi::apply(p, bias, m, nb, h, g, nbg);
+  }
+}
+
+}  // namespace
+
+int conv_gemm_pick_split(int M, int N, int K) {
+  // Fill the 256 CUs: tiles are 128x128 (or 256x64); split K when the grid is small and K is deep.
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int ksteps = K / 64;
+  if (tiles >= 192 || ksteps < 8) return 1;
+  int s = (384 + tiles - 1) / tiles;
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return s;
+}
+
+hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
+  if (p.K & 63) return hipErrorInvalidValue;
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  int split = p.ksplit > 0 ? p.ksplit : conv_gemm_pick_split(p.M, p.N, p.K);
+  while (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > partial_cap_bytes) --split;
+  if (!p.partial) split = 1;
+  p.ksplit = split;
+  // tile shape: 128x128 (2x2 waves) unless N is an odd multiple of 64 (e.g. 320) -> 256x64 (4x1 waves)
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 64) * 128);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
+    attr_done = true;
+  }
+  const bool narrow = ((p.N % 128) != 0 && (p.N % 128) <= 64) && p.M >= 256;
+  if (narrow) {
+    const int ntm = (p.M + 255) / 256, ntn = (p.N + 63) / 64;
+    dim3 grid(ntm * ntn, split);
+    hipLaunchKernelGGL((conv_gemm_kernel<4, 1>), grid, dim3(256), 2 * (256 + 64) * 128, stream, p);
+  } else {
+    const int ntm = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
+    dim3 grid(ntm * ntn, split);
+    hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, dim3(256), 2 * (128 + 128) * 128, stream, p);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (split > 1) {
+    const int ncols = (p.flags & CF_GEGLU) ? p.N / 2 : p.N;
+    const size_t total = (size_t)p.M * ((ncols + 3) / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    e = hipGetLastError();
+  }
+  return e;
+}

@@ -1,0 +1,558 @@
+// K6/K7/K9/K10/K12 — the HBM-bound side kernels of the guided DDIM loop (gfx950):
+// layout conversion, CFG + DDIM update and its VJP (generate_data.py:116-119), add_noise (:1176),
+// affine perturbation / SGD / L-inf projection of transform_guidance (:696, :721-728, :124-137),
+// direct-guidance update (:762), nearest-2x transpose (2x2 sum pool), GEGLU backward,
+// max-pool, bicubic 224 resize (A=-0.75, align_corners=False) and its transpose, GAP,
+// prototype energy + argmax + gradient (:707-717 / :747-759).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+#define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
+
+inline int nblocks(size_t n, int threads = 256, int cap = 8192) {
+  size_t b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, int ld, int dup, float scale) {
+  const size_t total = (size_t)(dup ? 2 * B : B) * HW * Cpad;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cpad);
+    const size_t row = i / Cpad;
+    const int pix = (int)(row % HW);
+    const int b = (int)((row / HW) % B);
+    const float v = c < C ? src[((size_t)b * C + c) * HW + pix] * scale : 0.f;
+    dst[row * ld + c] = f2bf(v);
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* src, int src_f32, float* dst, int B, int C, int HW, int ld, float scale,
+                                    float shift, int clamp, float lo, float hi) {
+  const size_t total = (size_t)B * C * HW;
+  GRID_STRIDE(i, total) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const size_t si = ((size_t)b * HW + pix) * ld + c;
+    float v = src_f32 ? ((const float*)src)[si] : bf2f(((const bf16_t*)src)[si]);
+    v = v * scale + shift;
+    if (clamp) v = fminf(fmaxf(v, lo), hi);
+    dst[i] = v;
+  }
+}
+
+__global__ void cfg_ddim_kernel(const float* eps2, int ld, const float* z, float* z_prev, float* x0, int B, int C, int HW,
+                                const float* coef) {
+  const float s = coef[0], sa = coef[1], s1m = coef[2], sap = coef[3], s1mp = coef[4];
+  const size_t total = (size_t)B * C * HW;
+  GRID_STRIDE(i, total) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const float eu = eps2[((size_t)b * HW + pix) * ld + c];
+    const float ec = eps2[((size_t)(B + b) * HW + pix) * ld + c];
+    const float eps = eu + s * (ec - eu);
+    const float x = (z[i] - s1m * eps) / sa;
+    if (x0) x0[i] = x;
+    z_prev[i] = sap * x + s1mp * eps;
+  }
+}
+
+__global__ void cfg_ddim_bwd_kernel(const float* g_x0, const float* g_zprev, bf16_t* g_eps2, int ld, float* g_z, int B, int C,
+                                    int HW, int Cpad, const float* coef) {
+  const float s = coef[0], sa = coef[1], s1m = coef[2], sap = coef[3], s1mp = coef[4];
+  const size_t total = (size_t)B * HW * Cpad;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cpad);
+    const size_t row = i / Cpad;
+    const int pix = (int)(row % HW);
+    const int b = (int)(row / HW);
+    float gu = 0.f, gc = 0.f;
+    if (c < C) {
+      const size_t zi = ((size_t)b * C + c) * HW + pix;
+      const float gx = g_x0 ? g_x0[zi] : 0.f;
+      const float gp = g_zprev ? g_zprev[zi] : 0.f;
+      const float h = gx + sap * gp;
+      const float ge = -s1m / sa * h + s1mp * gp;
+      g_z[zi] = h / sa;
+      gu = (1.f - s) * ge; gc = s * ge;
+    }
+    g_eps2[((size_t)b * HW + pix) * ld + c] = f2bf(gu);
+    g_eps2[((size_t)(B + b) * HW + pix) * ld + c] = f2bf(gc);
+  }
+}
+
+// g_z[b,c,pix] += gin[(b*HW+pix), c] + gin[((B+b)*HW+pix), c]   (backward of cat[z, z] + layout change)
+__global__ void dup_bwd_kernel(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate) {
+  const size_t total = (size_t)B * C * HW;
+  GRID_STRIDE(i, total) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const float v = bf2f(gin[((size_t)b * HW + pix) * ld + c]) + bf2f(gin[((size_t)(B + b) * HW + pix) * ld + c]);
+    g_z[i] = accumulate ? g_z[i] + v : v;
+  }
+}
+
+__global__ void axpby_kernel(const float* x, const float* n, float* out, size_t count, const float* coef) {
+  const float a = coef[0], b = coef[1];
+  GRID_STRIDE(i, count) out[i] = a * x[i] + b * n[i];
+}
+
+__global__ void sumpool_kernel(const bf16_t* src, int src_ld, bf16_t* dst, int dst_ld, int B, int H, int W, int C, int acc) {
+  const int VC = C >> 3;
+  const size_t total = (size_t)B * H * W * VC;
+  GRID_STRIDE(i, total) {
+    const int vc = (int)(i % VC);
+    const size_t pix = i / VC;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float v[8];
+        unpack8(*(const uint4*)(src + (((size_t)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * src_ld + vc * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += v[e];
+      }
+    bf16_t* d = dst + pix * dst_ld + vc * 8;
+    if (acc) {
+      float o[8];
+      unpack8(*(const uint4*)d, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += o[e];
+    }
+    *(uint4*)d = pack8(a);
+  }
+}
+
+__global__ void add_kernel(const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* y, int ldy, int M, int C) {
+  const int VC = C >> 3;
+  GRID_STRIDE(i, (size_t)M * VC) {
+    const int vc = (int)(i % VC);
+    const size_t m = i / VC;
+    float x[8], z[8];
+    unpack8(*(const uint4*)(a + m * lda + vc * 8), x);
+    if (b) {
+      unpack8(*(const uint4*)(b + m * ldb + vc * 8), z);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += z[e];
+    }
+    *(uint4*)(y + m * ldy + vc * 8) = pack8(x);
+  }
+}
+
+// y = dy * (mask > 0)
+__global__ void mask_kernel(const bf16_t* dy, int ldd, const bf16_t* mask, int ldm, bf16_t* y, int ldy, int M, int C) {
+  const int VC = C >> 3;
+  GRID_STRIDE(i, (size_t)M * VC) {
+    const int vc = (int)(i % VC);
+    const size_t m = i / VC;
+    float x[8], z[8];
+    unpack8(*(const uint4*)(dy + m * ldd + vc * 8), x);
+    unpack8(*(const uint4*)(mask + m * ldm + vc * 8), z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = z[e] > 0.f ? x[e] : 0.f;
+    *(uint4*)(y + m * ldy + vc * 8) = pack8(x);
+  }
+}
+
+// raw packed [M, 2F]: 32-column groups = 16 hidden | 16 gate. out col o <-> hidden (o/16)*32 + o%16, gate +16
+__global__ void geglu_bwd_kernel(const bf16_t* raw, int ld_raw, const bf16_t* dout, int ld_dout, bf16_t* draw, int ld_draw,
+                                 int M, int F) {
+  const int VC = F >> 3;
+  GRID_STRIDE(i, (size_t)M * VC) {
+    const int vc = (int)(i % VC);
+    const size_t m = i / VC;
+    const int o = vc * 8;
+    const int hc = (o >> 4) * 32 + (o & 15);
+    float h[8], g[8], d[8], dh[8], dg[8];
+    unpack8(*(const uint4*)(raw + m * ld_raw + hc), h);
+    unpack8(*(const uint4*)(raw + m * ld_raw + hc + 16), g);
+    unpack8(*(const uint4*)(dout + m * ld_dout + o), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dh[e] = d[e] * gelu_f(g[e]);
+      dg[e] = d[e] * h[e] * dgelu_f(g[e]);
+    }
+    *(uint4*)(draw + m * ld_draw + hc) = pack8(dh);
+    *(uint4*)(draw + m * ld_draw + hc + 16) = pack8(dg);
+  }
+}
+
+__global__ void maxpool_kernel(const bf16_t* x, bf16_t* y, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, VC = C >> 3;
+  GRID_STRIDE(i, (size_t)B * Ho * Wo * VC) {
+    const int vc = (int)(i % VC);
+    const size_t pix = i / VC;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+        if (iy < 0 || ix < 0 || iy >= H || ix >= W) continue;
+        float v[8];
+        unpack8(*(const uint4*)(x + (((size_t)b * H + iy) * W + ix) * C + vc * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    *(uint4*)(y + pix * C + vc * 8) = pack8(m);
+  }
+}
+
+// gradient goes to the first maximum of each window in (ky, kx) scan order (PyTorch CPU/CUDA max_pool2d).
+__global__ void maxpool_bwd_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, VC = C >> 3;
+  GRID_STRIDE(i, (size_t)B * H * W * VC) {
+    const int vc = (int)(i % VC);
+    const size_t pix = i / VC;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // windows (oy, ox) that contain (iy, ix): oy*2-1 <= iy <= oy*2+1
+    for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        float m[8]; int am[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; am[e] = -1; }
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = oy * 2 + ky - 1, xx = ox * 2 + kx - 1;
+            if (yy < 0 || xx < 0 || yy >= H || xx >= W) continue;
+            float v[8];
+            unpack8(*(const uint4*)(x + (((size_t)b * H + yy) * W + xx) * C + vc * 8), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (v[e] > m[e]) { m[e] = v[e]; am[e] = yy * W + xx; }
+          }
+        float d[8];
+        unpack8(*(const uint4*)(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + vc * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (am[e] == iy * W + ix) g[e] += d[e];
+      }
+    }
+    *(uint4*)(dx + pix * C + vc * 8) = pack8(g);
+  }
+}
+
+__device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+  const float A = -0.75f;
+  w[0] = cc2(t + 1.f, A); w[1] = cc1(t, A); w[2] = cc1(1.f - t, A); w[3] = cc2(2.f - t, A);
+}
+
+__global__ void bicubic_kernel(const bf16_t* src, int ld_s, bf16_t* dst, int ld_d, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                               int Cpad) {
+  const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+  GRID_STRIDE(i, (size_t)B * Hd * Wd) {
+    const int ox = (int)(i % Wd), oy = (int)((i / Wd) % Hd), b = (int)(i / ((size_t)Wd * Hd));
+    const float ry = sh * (oy + 0.5f) - 0.5f, rx = sw * (ox + 0.5f) - 0.5f;
+    const float fy = floorf(ry), fx = floorf(rx);
+    float wy[4], wx[4];
+    cubic_coeffs(ry - fy, wy); cubic_coeffs(rx - fx, wx);
+    const int iy = (int)fy, ix = (int)fx;
+    for (int c = 0; c < Cpad; ++c) {
+      float acc = 0.f;
+      if (c < C) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int yy = min(max(iy - 1 + a, 0), Hs - 1);
+          float r = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int xx = min(max(ix - 1 + q, 0), Ws - 1);
+            r += wx[q] * bf2f(src[(((size_t)b * Hs + yy) * Ws + xx) * ld_s + c]);
+          }
+          acc += wy[a] * r;
+        }
+      }
+      dst[i * ld_d + c] = f2bf(acc);
+    }
+  }
+}
+
+// Transposed bicubic as a gather over destination pixels whose 4x4 footprints (after border clamping) hit this
+// source pixel: deterministic, no atomics. For a down-scale factor s the candidate dst range is small.
+__global__ void bicubic_bwd_kernel(const bf16_t* ddst, int ld_d, bf16_t* dsrc, int ld_s, int B, int Hs, int Ws, int Hd, int Wd,
+                                   int C) {
+  const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+  GRID_STRIDE(i, (size_t)B * Hs * Ws) {
+    const int sx = (int)(i % Ws), sy = (int)((i / Ws) % Hs), b = (int)(i / ((size_t)Ws * Hs));
+    // dst rows whose taps (fy-1..fy+2, clamped) can touch sy: fy in [sy-2, sy+1] -> invert ry = sh*(d+.5)-.5
+    int dy_lo = (int)floorf((sy - 2 + 0.5f) / sh - 0.5f) - 1, dy_hi = (int)ceilf((sy + 2 + 0.5f) / sh - 0.5f) + 1;
+    int dx_lo = (int)floorf((sx - 2 + 0.5f) / sw - 0.5f) - 1, dx_hi = (int)ceilf((sx + 2 + 0.5f) / sw - 0.5f) + 1;
+    if (sy == 0) dy_lo = 0;
+    if (sy == Hs - 1) dy_hi = Hd - 1;
+    if (sx == 0) dx_lo = 0;
+    if (sx == Ws - 1) dx_hi = Wd - 1;
+    dy_lo = max(dy_lo, 0); dy_hi = min(dy_hi, Hd - 1); dx_lo = max(dx_lo, 0); dx_hi = min(dx_hi, Wd - 1);
+    float acc[4] = {0, 0, 0, 0};
+    for (int oy = dy_lo; oy <= dy_hi; ++oy) {
+      const float ry = sh * (oy + 0.5f) - 0.5f, fy = floorf(ry);
+      float wy[4]; cubic_coeffs(ry - fy, wy);
+      float wys = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wys += (min(max((int)fy - 1 + a, 0), Hs - 1) == sy) ? wy[a] : 0.f;
+      if (wys == 0.f) continue;
+      for (int ox = dx_lo; ox <= dx_hi; ++ox) {
+        const float rx = sw * (ox + 0.5f) - 0.5f, fx = floorf(rx);
+        float wx[4]; cubic_coeffs(rx - fx, wx);
+        float wxs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wxs += (min(max((int)fx - 1 + q, 0), Ws - 1) == sx) ? wx[q] : 0.f;
+        if (wxs == 0.f) continue;
+        const bf16_t* d = ddst + (((size_t)b * Hd + oy) * Wd + ox) * ld_d;
+        for (int c = 0; c < C && c < 4; ++c) acc[c] += wys * wxs * bf2f(d[c]);
+      }
+    }
+    for (int c = 0; c < C && c < 4; ++c) dsrc[i * ld_s + c] = f2bf(acc[c]);
+  }
+}
+
+__global__ void gap_kernel(const bf16_t* x, int ld, float* f, int B, int HW, int C) {
+  GRID_STRIDE(i, (size_t)B * C) {
+    const int c = (int)(i % C), b = (int)(i / C);
+    float s = 0.f;
+    for (int pxl = 0; pxl < HW; ++pxl) s += bf2f(x[((size_t)b * HW + pxl) * ld + c]);
+    f[i] = s / HW;
+  }
+}
+
+__global__ void gap_bwd_kernel(const float* gf, bf16_t* dx, int ld, int B, int HW, int C, const bf16_t* mask, int mask_ld) {
+  GRID_STRIDE(i, (size_t)B * HW * C) {
+    const int c = (int)(i % C);
+    const size_t row = i / C;
+    const int b = (int)(row / HW);
+    float v = gf[(size_t)b * C + c] / HW;
+    if (mask && !(bf2f(mask[row * mask_ld + c]) > 0.f)) v = 0.f;
+    dx[row * ld + c] = f2bf(v);
+  }
+}
+
+__device__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+// single block: loops over the batch so that the score accumulation order is fixed (deterministic)
+__global__ __launch_bounds__(256) void energy_kernel(const float* f, const float* Pc, const float* Pg, const int* targets, int B,
+                                                     int D, int K, float gs, float ls, int use_c, int use_g, int normalize,
+                                                     float weight, float* score_out, float* gf) {
+  __shared__ float red[8];
+  __shared__ float dots[64];
+  float score = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* fb = f + (size_t)b * D;
+    const int y = targets[b];
+    float nrm = 1.f;
+    if (normalize) {
+      float s = 0.f;
+      for (int d = threadIdx.x; d < D; d += blockDim.x) s += fb[d] * fb[d];
+      nrm = sqrtf(block_sum(s, red));
+    }
+    const float inv = 1.f / nrm;
+    float dc = 0.f, dg = 0.f;
+    int idx = 0;
+    const float* pc = Pc ? Pc + (size_t)y * D : nullptr;
+    if (use_c) {
+      float s = 0.f;
+      for (int d = threadIdx.x; d < D; d += blockDim.x) { const float t = fb[d] * inv - pc[d]; s += t * t; }
+      dc = sqrtf(block_sum(s, red));
+    }
+    const float* pg = nullptr;
+    if (use_g) {
+      for (int k = 0; k < K; ++k) {
+        const float* pk = Pg + ((size_t)y * K + k) * D;
+        float s = 0.f;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) s += fb[d] * inv * pk[d];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) dots[k] = s;
+      }
+      __syncthreads();
+      float best = dots[0];
+      for (int k = 1; k < K; ++k)
+        if (dots[k] > best) { best = dots[k]; idx = k; }   // first maximum, like torch.argmax
+      pg = Pg + ((size_t)y * K + idx) * D;
+      float s = 0.f;
+      for (int d = threadIdx.x; d < D; d += blockDim.x) { const float t = fb[d] * inv - pg[d]; s += t * t; }
+      dg = sqrtf(block_sum(s, red));
+    }
+    score += (use_c ? gs * dc : 0.f) + (use_g ? ls * dg : 0.f);
+    if (gf) {
+      // gradient wrt fhat, then through the optional normalisation
+      const float wc = use_c ? weight * gs / (B * dc) : 0.f, wg = use_g ? weight * ls / (B * dg) : 0.f;
+      float dotp = 0.f;
+      if (normalize) {
+        float s = 0.f;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+          const float fh = fb[d] * inv;
+          float g = 0.f;
+          if (use_c) g += wc * (fh - pc[d]);
+          if (use_g) g += wg * (fh - pg[d]);
+          s += g * fh;
+        }
+        dotp = block_sum(s, red);
+      }
+      for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float fh = fb[d] * inv;
+        float g = 0.f;
+        if (use_c) g += wc * (fh - pc[d]);
+        if (use_g) g += wg * (fh - pg[d]);
+        if (normalize) g = (g - fh * dotp) * inv;
+        gf[(size_t)b * D + d] = g;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) score_out[0] += weight * score / B;
+}
+
+__global__ void affine_kernel(const float* z, const float* e, const float* b, float* out, int BC, int HW) {
+  GRID_STRIDE(i, (size_t)BC * HW) {
+    const int bc = (int)(i / HW);
+    out[i] = z[i] * (1.f + e[bc]) + b[bc];
+  }
+}
+
+// one block per (b, c)
+__global__ __launch_bounds__(256) void transform_update_kernel(const float* z, const float* g, const float* e, const float* b,
+                                                               float* z_out, int HW, float rho, float c) {
+  __shared__ float red[8];
+  const int bc = blockIdx.x;
+  const float* zp = z + (size_t)bc * HW;
+  const float* gp = g + (size_t)bc * HW;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) { s0 += gp[i] * zp[i]; s1 += gp[i]; }
+  const float ge = block_sum(s0, red);
+  const float gb = block_sum(s1, red);
+  const float en = e[bc] - rho * ge, bn = b[bc] - rho * gb;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const float zz = zp[i];
+    float v = zz * (1.f + en) + bn;
+    const float lo = zz - c, hi = zz + c;
+    if (v < lo) v = lo;   // tensor_clamp: lower bound first (generate_data.py:129-132)
+    if (v > hi) v = hi;
+    z_out[(size_t)bc * HW + i] = v;
+  }
+}
+
+__global__ void sub_scaled_kernel(const float* a, const float* g, float* out, size_t n, float rho) {
+  GRID_STRIDE(i, n) out[i] = a[i] - rho * g[i];
+}
+__global__ void f32_to_bf16_kernel(const float* s, bf16_t* d, size_t n) { GRID_STRIDE(i, n) d[i] = f2bf(s[i]); }
+__global__ void fill_kernel(float* d, float v, size_t n) { GRID_STRIDE(i, n) d[i] = v; }
+__global__ void to_uint8_kernel(const float* nchw, uint8_t* hwc, int B, int C, int HW) {
+  GRID_STRIDE(i, (size_t)B * HW * C) {
+    const int c = (int)(i % C);
+    const size_t row = i / C;
+    const int pix = (int)(row % HW), b = (int)(row / HW);
+    float v = nchw[((size_t)b * C + c) * HW + pix];      // already in [0,1]
+    v = fminf(fmaxf(v * 255.f + 0.5f, 0.f), 255.f);      // torchvision save_image: mul(255).add_(0.5).clamp_(0,255).to(uint8)
+    hwc[i] = (uint8_t)v;
+  }
+}
+
+}  // namespace
+
+#define LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, s, __VA_ARGS__); return hipGetLastError()
+
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int H, int W, int Cpad, int ld, int dup,
+                                        float scale, hipStream_t s) {
+  LAUNCH(nchw_to_nhwc_kernel, (size_t)(dup ? 2 : 1) * B * H * W * Cpad, src, dst, B, C, H * W, Cpad, ld, dup, scale);
+}
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int src_f32, float* dst, int B, int C, int H, int W, int ld, float scale,
+                                   float shift, int clamp, float lo, float hi, hipStream_t s) {
+  LAUNCH(nhwc_to_nchw_kernel, (size_t)B * C * H * W, src, src_f32, dst, B, C, H * W, ld, scale, shift, clamp, lo, hi);
+}
+hipError_t launch_cfg_ddim(const float* eps2, int ld, const float* z, float* z_prev, float* x0, int B, int C, int HW,
+                           const float* coef_dev, hipStream_t s) {
+  LAUNCH(cfg_ddim_kernel, (size_t)B * C * HW, eps2, ld, z, z_prev, x0, B, C, HW, coef_dev);
+}
+hipError_t launch_cfg_ddim_bwd(const float* g_x0, const float* g_zprev, bf16_t* g_eps2, int ld, float* g_z, int B, int C, int HW,
+                               const float* coef_dev, hipStream_t s) {
+  LAUNCH(cfg_ddim_bwd_kernel, (size_t)B * HW * ld, g_x0, g_zprev, g_eps2, ld, g_z, B, C, HW, ld, coef_dev);
+}
+hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, hipStream_t s) {
+  LAUNCH(dup_bwd_kernel, (size_t)B * C * HW, gin, ld, g_z, B, C, HW, accumulate);
+}
+hipError_t launch_axpby(const float* x, const float* n, float* out, size_t count, const float* coef_dev, hipStream_t s) {
+  LAUNCH(axpby_kernel, count, x, n, out, count, coef_dev);
+}
+hipError_t launch_sumpool2x2(const bf16_t* src, int src_ld, bf16_t* dst, int dst_ld, int B, int H, int W, int C, int accumulate,
+                             hipStream_t s) {
+  LAUNCH(sumpool_kernel, (size_t)B * H * W * (C / 8), src, src_ld, dst, dst_ld, B, H, W, C, accumulate);
+}
+hipError_t launch_add_bf16(const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* y, int ldy, int M, int C, hipStream_t s) {
+  LAUNCH(add_kernel, (size_t)M * (C / 8), a, lda, b, ldb, y, ldy, M, C);
+}
+hipError_t launch_copy_bf16(const bf16_t* a, int lda, bf16_t* y, int ldy, int M, int C, hipStream_t s) {
+  LAUNCH(add_kernel, (size_t)M * (C / 8), a, lda, (const bf16_t*)nullptr, 0, y, ldy, M, C);
+}
+hipError_t launch_mask_bf16(const bf16_t* dy, int ldd, const bf16_t* mask, int ldm, bf16_t* y, int ldy, int M, int C,
+                            hipStream_t s) {
+  LAUNCH(mask_kernel, (size_t)M * (C / 8), dy, ldd, mask, ldm, y, ldy, M, C);
+}
+hipError_t launch_geglu_bwd(const bf16_t* raw, int ld_raw, const bf16_t* dout, int ld_dout, bf16_t* draw, int ld_draw, int M,
+                            int F, hipStream_t s) {
+  LAUNCH(geglu_bwd_kernel, (size_t)M * (F / 8), raw, ld_raw, dout, ld_dout, draw, ld_draw, M, F);
+}
+hipError_t launch_maxpool3x3s2(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, hipStream_t s) {
+  LAUNCH(maxpool_kernel, (size_t)B * (H / 2) * (W / 2) * (C / 8), x, y, B, H, W, C);
+}
+hipError_t launch_maxpool3x3s2_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C, hipStream_t s) {
+  LAUNCH(maxpool_bwd_kernel, (size_t)B * H * W * (C / 8), x, dy, dx, B, H, W, C);
+}
+hipError_t launch_bicubic(const bf16_t* src, int ld_s, bf16_t* dst, int ld_d, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                          int Cpad, hipStream_t s) {
+  LAUNCH(bicubic_kernel, (size_t)B * Hd * Wd, src, ld_s, dst, ld_d, B, Hs, Ws, Hd, Wd, C, Cpad);
+}
+hipError_t launch_bicubic_bwd(const bf16_t* ddst, int ld_d, bf16_t* dsrc, int ld_s, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                              hipStream_t s) {
+  if (C > 4) return hipErrorInvalidValue;
+  LAUNCH(bicubic_bwd_kernel, (size_t)B * Hs * Ws, ddst, ld_d, dsrc, ld_s, B, Hs, Ws, Hd, Wd, C);
+}
+hipError_t launch_gap(const bf16_t* x, int ld, float* f, int B, int HW, int C, hipStream_t s) {
+  LAUNCH(gap_kernel, (size_t)B * C, x, ld, f, B, HW, C);
+}
+hipError_t launch_gap_bwd(const float* gf, bf16_t* dx, int ld, int B, int HW, int C, const bf16_t* mask, int mask_ld,
+                          hipStream_t s) {
+  LAUNCH(gap_bwd_kernel, (size_t)B * HW * C, gf, dx, ld, B, HW, C, mask, mask_ld);
+}
+hipError_t launch_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K, float gs,
+                         float ls, int use_c, int use_g, int normalize, float weight, float* score_out, float* gf, hipStream_t s) {
+  if (K > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(energy_kernel, dim3(1), dim3(256), 0, s, f, Pc, Pg, targets, B, D, K, gs, ls, use_c, use_g, normalize, weight,
+                     score_out, gf);
+  return hipGetLastError();
+}
+hipError_t launch_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, hipStream_t s) {
+  LAUNCH(affine_kernel, (size_t)BC * HW, z, e, b, out, BC, HW);
+}
+hipError_t launch_transform_update(const float* z, const float* g, const float* e, const float* b, float* z_out, int BC, int HW,
+                                   float rho, float c, hipStream_t s) {
+  hipLaunchKernelGGL(transform_update_kernel, dim3(BC), dim3(256), 0, s, z, g, e, b, z_out, HW, rho, c);
+  return hipGetLastError();
+}
+hipError_t launch_sub_scaled(const float* a, const float* g, float* out, size_t n, float rho, hipStream_t s) {
+  LAUNCH(sub_scaled_kernel, n, a, g, out, n, rho);
+}
+hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) { LAUNCH(f32_to_bf16_kernel, n, src, dst, n); }
+hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s) { LAUNCH(fill_kernel, n, dst, v, n); }
+hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s) {
+  LAUNCH(to_uint8_kernel, (size_t)B * H * W * C, nchw, hwc, B, C, H * W);
+}

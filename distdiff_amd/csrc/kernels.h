@@ -1,0 +1,196 @@
+// Host-side launch interface of the hand-written gfx950 kernels.
+// Everything here enqueues on the given stream and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+
+// ----------------------------------------------------------------------------------------------
+// K1/K2/K8: implicit-GEMM convolution == GEMM == linear (bf16 MFMA, fp32 accumulate).
+//   out[m, n] = epilogue( alpha * sum_k A[m, k] * Wp[n, k] ),  m = (b, oy, ox) NHWC pixel,
+//   k = (tap, cin) with cin fastest, A gathered on the fly from the NHWC input (zero padding,
+//   optional fused nearest-2x upsample, optional stride-2, optional input-dilated "transposed"
+//   gather used for the dgrad of stride-2 convolutions).
+// ----------------------------------------------------------------------------------------------
+enum ConvFlags {
+  CF_BIAS = 1,       // + bias[n]          (fp32; optionally selected per timestep through bias_sel)
+  CF_RES = 2,        // + res[m, n]        (bf16)
+  CF_RELU = 4,       // max(., 0)
+  CF_GEGLU = 8,      // packed (hidden|gate) 16-column groups -> hidden * gelu(gate); N counts packed columns
+  CF_OUT_F32 = 16,   // store fp32 instead of bf16
+  CF_MASK = 32,      // multiply by (mask[m, n] > 0)   (ReLU backward)
+  CF_RES_F32 = 64,   // residual is fp32
+  CF_GEGLU_RAW = 128 // with CF_GEGLU: also store the raw packed pre-activation (bf16) to raw[m, N]
+};
+
+struct ConvGemmParams {
+  const bf16_t* x;      // input activations, NHWC, row stride x_ld elements
+  const bf16_t* w;      // packed weights [N][K], K contiguous, K % 64 == 0 (zero padded)
+  const int* taptab;    // ntaps entries: ((dy + 32) << 6) | (dx + 32), logical-input offset of each filter tap
+  void* y;              // output (bf16 or fp32), row stride y_ld
+  const float* bias;    // [N] fp32 or null
+  const int* bias_sel;  // optional device scalar: bias += (*bias_sel) * bias_stride
+  const void* res;      // residual or null
+  const bf16_t* mask;   // relu mask source or null
+  bf16_t* raw;          // GEGLU raw output or null
+  float* partial;       // split-K workspace [ksplit][M][N] fp32 (ksplit > 1)
+  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride;
+  int B, H, W;          // stored input geometry
+  int Ho, Wo;           // output geometry
+  int stride;           // output->logical-input stride (1 or 2)
+  int shift;            // 1: logical input is 2x the stored input (nearest upsample or dilation)
+  int parity;           // 1 with shift: only even logical coordinates are populated (transposed conv)
+  int cin, ntaps;       // channels per tap (multiple of 8), number of taps; K = roundup(ntaps*cin, 64)
+  int M, N, K;
+  int ksplit;
+  int flags;
+  float alpha;
+};
+
+// Chooses tile configuration / split-K from the shape. `partial_cap_bytes` bounds split-K workspace.
+hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream);
+// Preferred split for a shape (used by the engine to size the workspace).
+int conv_gemm_pick_split(int M, int N, int K);
+
+// ----------------------------------------------------------------------------------------------
+// K3: GroupNorm (+ optional SiLU) forward / backward on NHWC bf16.
+// ----------------------------------------------------------------------------------------------
+struct GroupNormParams {
+  const bf16_t* x; int x_ld;
+  bf16_t* y; int y_ld;
+  const float* gamma; const float* beta;   // [C]
+  float* stats;        // [B][G][2] (mean, rstd), written by fwd, read by bwd
+  float* scratch;      // [B][S][G][3] partial (count, mean, M2) / bwd partial sums
+  int B, HW, C, G;
+  float eps;
+  int silu;
+  // backward only
+  const bf16_t* dy; int dy_ld;
+  bf16_t* dx; int dx_ld;
+  int accumulate;      // dx += result
+};
+size_t groupnorm_scratch_bytes(int B, int G);
+hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream);
+hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------
+// K4: LayerNorm over the channel dim of [M, C] bf16 rows.
+// ----------------------------------------------------------------------------------------------
+struct LayerNormParams {
+  const bf16_t* x; int x_ld;
+  bf16_t* y; int y_ld;
+  const float* gamma; const float* beta;
+  float* stats;        // [M][2] mean, rstd
+  int M, C; float eps;
+  const bf16_t* dy; int dy_ld;
+  bf16_t* dx; int dx_ld;
+  int accumulate;
+};
+hipError_t launch_layernorm_fwd(const LayerNormParams& p, hipStream_t stream);
+hipError_t launch_layernorm_bwd(const LayerNormParams& p, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------
+// K5: flash attention forward / backward. Q rows [B*Nq, ldq], head h at column h*D.
+// ----------------------------------------------------------------------------------------------
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  bf16_t* o; float* lse;                    // lse [B][H][Nq] (natural log domain, of scaled scores)
+  int ldq, ldk, ldv, ldo;
+  int B, H, Nq, Nk, D;
+  float scale;
+  // backward
+  const bf16_t* d_o; int lddo;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;       // dk/dv may be null (cross attention: dQ only)
+  int lddq, lddk, lddv;
+  float* delta;                             // [B][H][Nq] scratch: rowsum(dO*O)
+  int accumulate_dq;                        // unused for now (dq is written)
+};
+hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
+hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------
+// K6/K7/K9/K10/K12: small HBM-bound kernels.
+// ----------------------------------------------------------------------------------------------
+// NCHW fp32 [B,C,H,W] -> NHWC bf16 [B*H*W, ld] (channels >= C zero-filled up to Cpad); dup copies
+// the batch twice (CFG: cat[z, z]).  scale multiplies.
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int H, int W, int Cpad, int ld,
+                                        int dup, float scale, hipStream_t s);
+// NHWC (bf16 or fp32) [B*H*W, ld] -> NCHW fp32 [B,C,H,W];  out = in * scale + shift, optional clamp to [lo, hi]
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int src_f32, float* dst, int B, int C, int H, int W, int ld,
+                                   float scale, float shift, int clamp, float lo, float hi, hipStream_t s);
+// CFG + DDIM step (generate_data.py:116-119): eps2 NHWC fp32 [2B*HW, ld] (uncond first), z NCHW fp32
+//   coef = {guidance_scale, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev}
+hipError_t launch_cfg_ddim(const float* eps2, int ld, const float* z, float* z_prev, float* x0, int B, int C, int HW,
+                           const float* coef_dev, hipStream_t s);
+// backward of cfg_ddim wrt (z via direct path) and eps2: see DESIGN.md / SURVEY appendix A
+//   g_x0, g_zprev NCHW fp32 (either may be null) -> g_eps2 NHWC bf16 [2B*HW, ld] and g_z_direct NCHW fp32
+hipError_t launch_cfg_ddim_bwd(const float* g_x0, const float* g_zprev, bf16_t* g_eps2, int ld, float* g_z, int B, int C,
+                               int HW, const float* coef_dev, hipStream_t s);
+// backward of cat[z, z] + NCHW->NHWC: g_z[b,c,pix] (+)= gin[b*HW+pix, c] + gin[(B+b)*HW+pix, c]
+hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, hipStream_t s);
+// y = dy * (mask > 0)  (ReLU backward)
+hipError_t launch_mask_bf16(const bf16_t* dy, int ldd, const bf16_t* mask, int ldm, bf16_t* y, int ldy, int M, int C,
+                            hipStream_t s);
+// add_noise: out = sa * x + sb * n   (fp32, n elements), coefficients from device memory {sa, sb}
+hipError_t launch_axpby(const float* x, const float* n, float* out, size_t count, const float* coef_dev, hipStream_t s);
+// 2x2 sum pooling of NHWC bf16 (backward of the fused nearest-2x upsample): [B,2H,2W,C] -> [B,H,W,C]
+hipError_t launch_sumpool2x2(const bf16_t* src, int src_ld, bf16_t* dst, int dst_ld, int B, int H, int W, int C,
+                             int accumulate, hipStream_t s);
+// y = a + b (bf16 rows), used where a fan-in cannot be fused into an epilogue
+hipError_t launch_add_bf16(const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* y, int ldy, int M, int C,
+                           hipStream_t s);
+// copy rows (bf16) with strides
+hipError_t launch_copy_bf16(const bf16_t* a, int lda, bf16_t* y, int ldy, int M, int C, hipStream_t s);
+// GEGLU backward: raw packed [M, 2F] (16-col groups hidden|gate), dout [M, F] -> draw [M, 2F] packed
+hipError_t launch_geglu_bwd(const bf16_t* raw, int ld_raw, const bf16_t* dout, int ld_dout, bf16_t* draw, int ld_draw,
+                            int M, int F, hipStream_t s);
+// max pool 3x3 stride 2 pad 1 NHWC bf16, and its backward (recomputes the argmax: first max in scan order)
+hipError_t launch_maxpool3x3s2(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_maxpool3x3s2_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C,
+                                   hipStream_t s);
+// bicubic (A=-0.75, align_corners=False, no antialias) NHWC: src [B,Hs,Ws,ld_s] (C real channels) -> dst [B,Hd,Wd,ld_d]
+// channels >= C in dst are zero-filled up to Cpad.
+hipError_t launch_bicubic(const bf16_t* src, int ld_s, bf16_t* dst, int ld_d, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                          int Cpad, hipStream_t s);
+// transpose of the above: dsrc [B,Hs,Ws,C] (+)= sum of taps of ddst
+hipError_t launch_bicubic_bwd(const bf16_t* ddst, int ld_d, bf16_t* dsrc, int ld_s, int B, int Hs, int Ws, int Hd, int Wd,
+                              int C, hipStream_t s);
+// global average pool [B, HW, C] bf16 -> f [B, C] fp32 ; backward broadcasts g/HW as bf16
+hipError_t launch_gap(const bf16_t* x, int ld, float* f, int B, int HW, int C, hipStream_t s);
+hipError_t launch_gap_bwd(const float* gf, bf16_t* dx, int ld, int B, int HW, int C, const bf16_t* mask, int mask_ld,
+                          hipStream_t s);
+// energy (generate_data.py:707-717 / 747-759) and its gradient wrt f.
+//   f [B,D] fp32, Pc [Ccls,D], Pg [Ccls,K,D], targets [B] int32. normalize: direct-guidance L2-normalise first.
+//   score_out[0] += weight * (gs*mean||f-pc|| + ls*mean||f-pg*||);  gf [B,D] = weight * dE/df
+hipError_t launch_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K,
+                         float gs, float ls, int use_c, int use_g, int normalize, float weight, float* score_out,
+                         float* gf, hipStream_t s);
+// transform guidance update (generate_data.py:696, 721-728): per (b,c): ge = sum_hw g*z, gb = sum_hw g;
+//   e -= rho*ge, b -= rho*gb ; z_out = clamp(z*(1+e)+b, z-c, z+c) (lower bound first)
+hipError_t launch_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, hipStream_t s);
+hipError_t launch_transform_update(const float* z, const float* g, const float* e, const float* b, float* z_out, int BC,
+                                   int HW, float rho, float c, hipStream_t s);
+// out = a - rho * g  (direct guidance :762)
+hipError_t launch_sub_scaled(const float* a, const float* g, float* out, size_t n, float rho, hipStream_t s);
+// NHWC bf16 [M, ld] (first C channels) -> NCHW fp32, used for gradients wrt latents
+// fp32 -> bf16 pack rows (weights upload helpers)
+hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s);
+// (x/2+0.5).clamp(0,1)*255+0.5 -> uint8 HWC (output stage, generate_data.py:1227 + save_image quantisation)
+hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s);
+
+// ----------------------------------------------------------------------------------------------
+// host-side weight packing (weights.cpp)
+// ----------------------------------------------------------------------------------------------
+struct PackedConv {
+  int N, K, cin, ntaps;   // GEMM N, padded K, padded channels per tap, taps
+};
+// mode 0: forward conv/linear weights [Cout][Cin][KH][KW] -> [N=Cout][K], taps (ky-pad, kx-pad)
+// mode 1: input-gradient (dgrad) weights               -> [N=Cin][K=(tap, cout)], taps (pad-ky, pad-kx)
+// geglu: the Cout dimension is permuted into 32-wide (16 hidden | 16 gate) groups (see CF_GEGLU)
+PackedConv pack_conv_shape(int Cout, int Cin, int KH, int KW, int mode);
+void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu, bf16_t* wp, int* taptab);
+int geglu_perm(int packed_index, int F);  // packed column -> original row of the [2F] projection
+bf16_t host_f2bf(float f);
+float host_bf2f(bf16_t v);

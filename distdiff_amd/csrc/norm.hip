@@ -1,0 +1,306 @@
+// K3/K4 — GroupNorm(+SiLU) and LayerNorm forward/backward on NHWC bf16 rows (gfx950).
+// Replaces torch.nn.GroupNorm / F.silu / LayerNorm inside diffusers' ResnetBlock2D, Transformer2DModel,
+// AutoencoderKL decoder (reference call sites generate_data.py:112, :701) and their autograd backward (:721).
+// HBM-bound: 16-byte vector loads, fp32 statistics, deterministic two-stage reductions (no float atomics
+// to global memory, so results are bitwise reproducible run to run).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SPLIT = 64;
+
+__host__ __device__ inline int gn_split(int HW) {
+  int s = HW / 256;  // >= 256 rows per block
+  if (s < 1) s = 1;
+  if (s > GN_MAX_SPLIT) s = GN_MAX_SPLIT;
+  return s;
+}
+
+// Pass 1 (fwd): per (b, split, group) partial (count, mean, M2).
+// Pass 1 (bwd): per (b, split, group) partial (s1 = sum dxhat, s2 = sum dxhat*xhat).
+template <bool BWD>
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GroupNormParams p) {
+  extern __shared__ float sh[];  // [2][C]
+  const int C = p.C, G = p.G, cpg = C / G, VC = C >> 3;
+  const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+  const int rows_per = (p.HW + S - 1) / S;
+  const int row_begin = s * rows_per, row_end = min(p.HW, row_begin + rows_per);
+  for (int c = threadIdx.x; c < 2 * C; c += GN_THREADS) sh[c] = 0.f;
+  __syncthreads();
+  const int VCt = min(VC, GN_THREADS);
+  const int R = GN_THREADS / VCt;
+  const int my_r = threadIdx.x / VCt, my_vc0 = threadIdx.x % VCt;
+  if (my_r < R) {
+    for (int vc = my_vc0; vc < VC; vc += VCt) {
+      float a0[8], a1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+      float ga[8], be[8], mean[8], rstd[8];
+      if (BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = vc * 8 + e, g = c / cpg;
+          ga[e] = p.gamma[c]; be[e] = p.beta[c];
+          mean[e] = p.stats[((size_t)b * G + g) * 2]; rstd[e] = p.stats[((size_t)b * G + g) * 2 + 1];
+        }
+      }
+      for (int row = row_begin + my_r; row < row_end; row += R) {
+        const size_t pix = (size_t)b * p.HW + row;
+        float xv[8];
+        unpack8(*(const uint4*)(p.x + pix * p.x_ld + vc * 8), xv);
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
+        } else {
+          float dv[8];
+          unpack8(*(const uint4*)(p.dy + pix * p.dy_ld + vc * 8), dv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - mean[e]) * rstd[e];
+            float d = dv[e];
+            if (p.silu) d *= dsilu_f(xh * ga[e] + be[e]);
+            d *= ga[e];
+            a0[e] += d; a1[e] += d * xh;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sh[vc * 8 + e], a0[e]);       // LDS float add
+        atomicAdd(&sh[C + vc * 8 + e], a1[e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += GN_THREADS) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { t0 += sh[c]; t1 += sh[C + c]; }
+    float* out = p.scratch + (((size_t)b * S + s) * G + g) * 3;
+    if (!BWD) {
+      const float n = (float)(row_end - row_begin) * cpg;
+      const float m = n > 0 ? t0 / n : 0.f;
+      out[0] = n; out[1] = m; out[2] = fmaxf(t1 - t0 * m, 0.f);  // M2 = sumsq - n*mean^2
+    } else {
+      out[0] = t0; out[1] = t1; out[2] = 0.f;
+    }
+  }
+}
+
+// Pass 2: merge partials, build per-channel affine in LDS, apply.
+template <bool BWD>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p, int S) {
+  extern __shared__ float sh[];  // fwd: a[C], sh[C] ; bwd: 4 x [C] + 2 x [G]
+  const int C = p.C, G = p.G, cpg = C / G, VC = C >> 3;
+  const int b = blockIdx.y;
+  float* A = sh;          // fwd: scale ; bwd: rstd*gamma
+  float* Bv = sh + C;     // fwd: shift ; bwd: mean
+  float* Cv = sh + 2 * C; // bwd: rstd
+  float* Dv = sh + 3 * C; // bwd: c1 = s1/n*rstd ... per channel
+  float* Ev = sh + 4 * C; // bwd: c2
+  for (int g = threadIdx.x; g < G; g += GN_THREADS) {
+    if (!BWD) {
+      // Chan et al. parallel merge of (n, mean, M2)
+      float n = 0.f, mean = 0.f, M2 = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float* in = p.scratch + (((size_t)b * S + s) * G + g) * 3;
+        const float nb = in[0], mb = in[1], M2b = in[2];
+        if (nb > 0.f) {
+          const float nn = n + nb, d = mb - mean;
+          mean += d * (nb / nn);
+          M2 += M2b + d * d * (n * nb / nn);
+          n = nn;
+        }
+      }
+      const float var = M2 / n;
+      const float rstd = rsqrtf(var + p.eps);
+      if (blockIdx.x == 0) {
+        p.stats[((size_t)b * G + g) * 2] = mean;
+        p.stats[((size_t)b * G + g) * 2 + 1] = rstd;
+      }
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const float a = rstd * p.gamma[c];
+        A[c] = a; Bv[c] = p.beta[c] - mean * a;
+      }
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float* in = p.scratch + (((size_t)b * S + s) * G + g) * 3;
+        s1 += in[0]; s2 += in[1];
+      }
+      const float n = (float)p.HW * cpg;
+      const float mean = p.stats[((size_t)b * G + g) * 2], rstd = p.stats[((size_t)b * G + g) * 2 + 1];
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        A[c] = p.gamma[c]; Bv[c] = mean; Cv[c] = rstd; Dv[c] = s1 / n; Ev[c] = s2 / n;
+      }
+    }
+  }
+  __syncthreads();
+  const int rows_per = (p.HW + gridDim.x - 1) / gridDim.x;
+  const int row_begin = blockIdx.x * rows_per, row_end = min(p.HW, row_begin + rows_per);
+  const int total = (row_end - row_begin) * VC;
+  for (int idx = threadIdx.x; idx < total; idx += GN_THREADS) {
+    const int row = row_begin + idx / VC, vc = idx % VC;
+    const size_t pix = (size_t)b * p.HW + row;
+    float xv[8], ov[8];
+    unpack8(*(const uint4*)(p.x + pix * p.x_ld + vc * 8), xv);
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = vc * 8 + e;
+        float y = xv[e] * A[c] + Bv[c];
+        ov[e] = p.silu ? silu_f(y) : y;
+      }
+      *(uint4*)(p.y + pix * p.y_ld + vc * 8) = pack8(ov);
+    } else {
+      float dv[8];
+      unpack8(*(const uint4*)(p.dy + pix * p.dy_ld + vc * 8), dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = vc * 8 + e;
+        const float xh = (xv[e] - Bv[c]) * Cv[c];
+        float d = dv[e];
+        if (p.silu) d *= dsilu_f(xh * A[c] + p.beta[c]);
+        d *= A[c];
+        ov[e] = Cv[c] * (d - Dv[c] - xh * Ev[c]);
+      }
+      bf16_t* dst = p.dx + pix * p.dx_ld + vc * 8;
+      if (p.accumulate) {
+        float old[8];
+        unpack8(*(const uint4*)dst, old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] += old[e];
+      }
+      *(uint4*)dst = pack8(ov);
+    }
+  }
+}
+
+// ---------------- LayerNorm: one wave per row, up to 4 x 64 x 8 = 2048 channels ----------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void ln_kernel(LayerNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int VC = p.C >> 3;
+  float xv[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < VC) {
+      unpack8(*(const uint4*)(p.x + (size_t)row * p.x_ld + vc * 8), xv[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xv[i][e];
+    }
+  }
+  float mean, rstd;
+  if (!BWD) {
+    mean = wave_sum(s) / p.C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < VC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; v += d * d; }
+      }
+    }
+    rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
+    if (lane == 0 && p.stats) { p.stats[(size_t)row * 2] = mean; p.stats[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < VC) {
+        float ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = vc * 8 + e;
+          ov[e] = (xv[i][e] - mean) * rstd * p.gamma[c] + p.beta[c];
+        }
+        *(uint4*)(p.y + (size_t)row * p.y_ld + vc * 8) = pack8(ov);
+      }
+    }
+  } else {
+    mean = p.stats[(size_t)row * 2]; rstd = p.stats[(size_t)row * 2 + 1];
+    float dv[4][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < VC) {
+        unpack8(*(const uint4*)(p.dy + (size_t)row * p.dy_ld + vc * 8), dv[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = vc * 8 + e;
+          const float xh = (xv[i][e] - mean) * rstd;
+          const float d = dv[i][e] * p.gamma[c];
+          dv[i][e] = d; xv[i][e] = xh;
+          s1 += d; s2 += d * xh;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / p.C; s2 = wave_sum(s2) / p.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < VC) {
+        float ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        bf16_t* dst = p.dx + (size_t)row * p.dx_ld + vc * 8;
+        if (p.accumulate) {
+          float old[8];
+          unpack8(*(const uint4*)dst, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] += old[e];
+        }
+        *(uint4*)dst = pack8(ov);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t groupnorm_scratch_bytes(int B, int G) { return (size_t)B * GN_MAX_SPLIT * G * 3 * sizeof(float); }
+
+static hipError_t gn_check(const GroupNormParams& p) {
+  if (p.C % 8 || p.C % p.G || (p.x_ld & 7)) return hipErrorInvalidValue;
+  return hipSuccess;
+}
+
+hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream) {
+  if (gn_check(p) != hipSuccess || (p.y_ld & 7)) return hipErrorInvalidValue;
+  const int S = gn_split(p.HW);
+  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(S, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p);
+  int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
+  if (ablocks < 1) ablocks = 1;
+  if (ablocks > 512) ablocks = 512;
+  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(ablocks, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p, S);
+  return hipGetLastError();
+}
+
+hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream) {
+  if (gn_check(p) != hipSuccess || (p.dy_ld & 7) || (p.dx_ld & 7)) return hipErrorInvalidValue;
+  const int S = gn_split(p.HW);
+  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(S, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p);
+  int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
+  if (ablocks < 1) ablocks = 1;
+  if (ablocks > 512) ablocks = 512;
+  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(ablocks, p.B), dim3(GN_THREADS), 5 * p.C * sizeof(float), stream, p, S);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_fwd(const LayerNormParams& p, hipStream_t stream) {
+  if (p.C % 8 || p.C > 2048 || (p.x_ld & 7) || (p.y_ld & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((ln_kernel<false>), dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_bwd(const LayerNormParams& p, hipStream_t stream) {
+  if (p.C % 8 || p.C > 2048 || (p.x_ld & 7) || (p.dy_ld & 7) || (p.dx_ld & 7) || !p.stats) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((ln_kernel<true>), dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}

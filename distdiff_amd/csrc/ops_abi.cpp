@@ -1,0 +1,72 @@
+// extern "C" op-level entry points (include/distdiff_hip_ops.h): thin forwards to the launchers.
+#include "kernels.h"
+#include "../../include/distdiff_hip_ops.h"
+
+#define S(x) ((hipStream_t)(x))
+extern "C" {
+int dd_op_conv_gemm(const ConvGemmParams* p, size_t cap, void* st) { return (int)launch_conv_gemm(*p, cap, S(st)); }
+int dd_op_groupnorm_fwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_fwd(*p, S(st)); }
+int dd_op_groupnorm_bwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_bwd(*p, S(st)); }
+size_t dd_op_groupnorm_scratch_bytes(int B, int G) { return groupnorm_scratch_bytes(B, G); }
+int dd_op_layernorm_fwd(const LayerNormParams* p, void* st) { return (int)launch_layernorm_fwd(*p, S(st)); }
+int dd_op_layernorm_bwd(const LayerNormParams* p, void* st) { return (int)launch_layernorm_bwd(*p, S(st)); }
+int dd_op_attention_fwd(const AttnParams* p, void* st) { return (int)launch_attention_fwd(*p, S(st)); }
+int dd_op_attention_bwd(const AttnParams* p, void* st) { return (int)launch_attention_bwd(*p, S(st)); }
+
+int dd_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu, uint16_t* wp,
+                        int* taptab, int* out4) {
+  const PackedConv s = pack_conv_shape(Cout, Cin, KH, KW, mode);
+  if (out4) { out4[0] = s.N; out4[1] = s.K; out4[2] = s.cin; out4[3] = s.ntaps; }
+  if (wp) pack_conv_weight(w, Cout, Cin, KH, KW, pad, mode, geglu, wp, taptab);
+  return 0;
+}
+int dd_op_nchw_f32_to_nhwc_bf16(const float* src, uint16_t* dst, int B, int C, int H, int W, int Cpad, int ld, int dup,
+                                float scale, void* st) {
+  return (int)launch_nchw_f32_to_nhwc_bf16(src, dst, B, C, H, W, Cpad, ld, dup, scale, S(st));
+}
+int dd_op_nhwc_to_nchw_f32(const void* src, int src_f32, float* dst, int B, int C, int H, int W, int ld, float scale, float shift,
+                           int clamp, float lo, float hi, void* st) {
+  return (int)launch_nhwc_to_nchw_f32(src, src_f32, dst, B, C, H, W, ld, scale, shift, clamp, lo, hi, S(st));
+}
+int dd_op_cfg_ddim(const float* eps2, int ld, const float* z, float* z_prev, float* x0, int B, int C, int HW, const float* coef,
+                   void* st) {
+  return (int)launch_cfg_ddim(eps2, ld, z, z_prev, x0, B, C, HW, coef, S(st));
+}
+int dd_op_cfg_ddim_bwd(const float* g_x0, const float* g_zprev, uint16_t* g_eps2, int ld, float* g_z, int B, int C, int HW,
+                       const float* coef, void* st) {
+  return (int)launch_cfg_ddim_bwd(g_x0, g_zprev, g_eps2, ld, g_z, B, C, HW, coef, S(st));
+}
+int dd_op_sumpool2x2(const uint16_t* src, int src_ld, uint16_t* dst, int dst_ld, int B, int H, int W, int C, int acc, void* st) {
+  return (int)launch_sumpool2x2(src, src_ld, dst, dst_ld, B, H, W, C, acc, S(st));
+}
+int dd_op_geglu_bwd(const uint16_t* raw, int ld_raw, const uint16_t* dout, int ld_dout, uint16_t* draw, int ld_draw, int M, int F,
+                    void* st) {
+  return (int)launch_geglu_bwd(raw, ld_raw, dout, ld_dout, draw, ld_draw, M, F, S(st));
+}
+int dd_op_maxpool3x3s2(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, void* st) {
+  return (int)launch_maxpool3x3s2(x, y, B, H, W, C, S(st));
+}
+int dd_op_maxpool3x3s2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int B, int H, int W, int C, void* st) {
+  return (int)launch_maxpool3x3s2_bwd(x, dy, dx, B, H, W, C, S(st));
+}
+int dd_op_bicubic(const uint16_t* src, int ld_s, uint16_t* dst, int ld_d, int B, int Hs, int Ws, int Hd, int Wd, int C, int Cpad,
+                  void* st) {
+  return (int)launch_bicubic(src, ld_s, dst, ld_d, B, Hs, Ws, Hd, Wd, C, Cpad, S(st));
+}
+int dd_op_bicubic_bwd(const uint16_t* ddst, int ld_d, uint16_t* dsrc, int ld_s, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                      void* st) {
+  return (int)launch_bicubic_bwd(ddst, ld_d, dsrc, ld_s, B, Hs, Ws, Hd, Wd, C, S(st));
+}
+int dd_op_gap(const uint16_t* x, int ld, float* f, int B, int HW, int C, void* st) { return (int)launch_gap(x, ld, f, B, HW, C, S(st)); }
+int dd_op_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K, float gs, float ls,
+                 int use_c, int use_g, int normalize, float weight, float* score_out, float* gf, void* st) {
+  return (int)launch_energy(f, Pc, Pg, targets, B, D, K, gs, ls, use_c, use_g, normalize, weight, score_out, gf, S(st));
+}
+int dd_op_transform_update(const float* z, const float* g, const float* e, const float* b, float* z_out, int BC, int HW, float rho,
+                           float c, void* st) {
+  return (int)launch_transform_update(z, g, e, b, z_out, BC, HW, rho, c, S(st));
+}
+int dd_op_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, void* st) {
+  return (int)launch_affine(z, e, b, out, BC, HW, S(st));
+}
+}

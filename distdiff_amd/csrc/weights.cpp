@@ -1,0 +1,52 @@
+// Host-side weight pre-packing for the implicit-GEMM kernel (conv_gemm.hip): OIHW fp32 -> [N][K] bf16 with
+// k = (tap, cin) and the per-tap offset table; transposed + flipped packing for the input-gradient GEMMs.
+#include <string.h>
+#include "kernels.h"
+
+bf16_t host_f2bf(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+float host_bf2f(bf16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int geglu_perm(int pr, int F) {
+  const int group = pr >> 5, within = pr & 31;
+  return within < 16 ? group * 16 + within : F + group * 16 + (within - 16);
+}
+
+PackedConv pack_conv_shape(int Cout, int Cin, int KH, int KW, int mode) {
+  PackedConv s;
+  const int cin = mode == 0 ? Cin : Cout;
+  s.N = mode == 0 ? Cout : Cin;
+  s.cin = (cin + 7) / 8 * 8;
+  s.ntaps = KH * KW;
+  s.K = (s.ntaps * s.cin + 63) / 64 * 64;
+  return s;
+}
+
+void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu, bf16_t* wp, int* taptab) {
+  const PackedConv s = pack_conv_shape(Cout, Cin, KH, KW, mode);
+  memset(wp, 0, (size_t)s.N * s.K * sizeof(bf16_t));
+  const int F = Cout / 2;
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx) {
+      const int tap = ky * KW + kx;
+      const int dy = mode == 0 ? ky - pad : pad - ky, dx = mode == 0 ? kx - pad : pad - kx;
+      taptab[tap] = ((dy + 32) << 6) | (dx + 32);
+    }
+  if (mode == 0) {
+    for (int n = 0; n < Cout; ++n) {
+      const int on = geglu ? geglu_perm(n, F) : n;
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < KH * KW; ++t) wp[(size_t)n * s.K + t * s.cin + c] = host_f2bf(w[((size_t)on * Cin + c) * KH * KW + t]);
+    }
+  } else {
+    for (int c = 0; c < Cin; ++c)
+      for (int n = 0; n < Cout; ++n) {
+        const int on = geglu ? geglu_perm(n, F) : n;
+        for (int t = 0; t < KH * KW; ++t) wp[(size_t)c * s.K + t * s.cin + n] = host_f2bf(w[((size_t)on * Cin + c) * KH * KW + t]);
+      }
+  }
+}

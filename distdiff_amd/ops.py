@@ -1,0 +1,169 @@
+"""Pythonic wrappers over the op-level C ABI (include/distdiff_hip_ops.h) on torch device tensors.
+
+Used by the parity tests and for debugging; the production loop goes through distdiff_amd.engine.
+Tensors are NHWC bf16 (a [pixels, C] matrix) unless stated. Nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, AttnParams,
+                   ConvGemmParams, GroupNormParams, LayerNormParams, check)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class PackedConv:
+    """Device copy of pre-packed weights for one conv/linear (forward or dgrad form)."""
+
+    def __init__(self, w_oihw, pad, mode=0, geglu=False, bias=None, device="cuda"):
+        w = w_oihw.detach().float().contiguous().cpu()
+        if w.dim() == 2:
+            w = w[:, :, None, None].contiguous()
+        Cout, Cin, KH, KW = w.shape
+        out4 = (C.c_int * 4)()
+        L = _lib.lib()
+        L.dd_pack_conv_weight(C.c_void_p(w.data_ptr()), Cout, Cin, KH, KW, pad, mode, int(geglu), None, None, out4)
+        self.N, self.K, self.cin, self.ntaps = out4[0], out4[1], out4[2], out4[3]
+        wp = np.zeros((self.N, self.K), dtype=np.uint16)
+        tt = np.zeros((self.ntaps,), dtype=np.int32)
+        L.dd_pack_conv_weight(C.c_void_p(w.data_ptr()), Cout, Cin, KH, KW, pad, mode, int(geglu),
+                              wp.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), out4)
+        self.w = torch.from_numpy(wp.view(np.int16)).to(device).view(torch.bfloat16)
+        self.taptab = torch.from_numpy(tt).to(device)
+        self.geglu = geglu
+        self.bias = None
+        if bias is not None:
+            b = bias.detach().float().cpu()
+            if geglu:
+                F = Cout // 2
+                perm = [(p // 32) * 16 + (p % 32) if (p % 32) < 16 else F + (p // 32) * 16 + (p % 32 - 16) for p in range(Cout)]
+                b = b[perm]
+            self.bias = b.to(device)
+
+
+def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
+              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None):
+    """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)]."""
+    p = ConvGemmParams()
+    M = B * Ho * Wo
+    ncols = pk.N // 2 if pk.geglu else pk.N
+    if y is None:
+        y = torch.empty((M, ncols), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    p.x, p.w, p.taptab, p.y = _ptr(x), _ptr(pk.w), _ptr(pk.taptab), _ptr(y)
+    p.x_ld = x_ld if x_ld is not None else x.stride(0)
+    p.y_ld = y.stride(0)
+    flags = 0
+    if pk.bias is not None:
+        flags |= CF_BIAS
+        p.bias = _ptr(pk.bias)
+    if res is not None:
+        flags |= CF_RES
+        if res.dtype == torch.float32:
+            flags |= CF_RES_F32
+        p.res, p.res_ld = _ptr(res), res.stride(0)
+    if mask is not None:
+        flags |= CF_MASK
+        p.mask, p.mask_ld = _ptr(mask), mask.stride(0)
+    if relu:
+        flags |= CF_RELU
+    if out_f32:
+        flags |= CF_OUT_F32
+    if pk.geglu:
+        flags |= CF_GEGLU
+        if raw is not None:
+            flags |= CF_GEGLU_RAW
+            p.raw, p.raw_ld = _ptr(raw), raw.stride(0)
+    cap = 0
+    if ksplit != 1:
+        if partial is None:
+            partial = torch.empty((max(ksplit, 16) * M * pk.N,), device=x.device, dtype=torch.float32)
+        p.partial = _ptr(partial)
+        cap = partial.numel() * 4
+    p.B, p.H, p.W, p.Ho, p.Wo, p.stride, p.shift, p.parity = B, H, W, Ho, Wo, stride, shift, parity
+    p.cin, p.ntaps, p.M, p.N, p.K = pk.cin, pk.ntaps, M, pk.N, pk.K
+    p.ksplit, p.flags, p.alpha = ksplit, flags, alpha
+    check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
+    return y
+
+
+def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None):
+    Cc = x.shape[1]
+    L = _lib.lib()
+    p = GroupNormParams()
+    y = torch.empty_like(x)
+    scratch = torch.empty((L.dd_op_groupnorm_scratch_bytes(B, G) // 4,), device=x.device, dtype=torch.float32)
+    if stats is None:
+        stats = torch.empty((B, G, 2), device=x.device, dtype=torch.float32)
+    p.x, p.x_ld, p.y, p.y_ld = _ptr(x), x.stride(0), _ptr(y), y.stride(0)
+    p.gamma, p.beta, p.stats, p.scratch = _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(scratch)
+    p.B, p.HW, p.C, p.G, p.eps, p.silu = B, HW, Cc, G, eps, int(silu)
+    if dy is None:
+        check(L.dd_op_groupnorm_fwd(C.byref(p), _stream()), "gn_fwd")
+        return y, stats
+    dx = torch.empty_like(x)
+    p.dy, p.dy_ld, p.dx, p.dx_ld, p.accumulate = _ptr(dy), dy.stride(0), _ptr(dx), dx.stride(0), 0
+    check(L.dd_op_groupnorm_bwd(C.byref(p), _stream()), "gn_bwd")
+    return dx
+
+
+def layernorm(x, gamma, beta, eps, dy=None, stats=None):
+    M, Cc = x.shape
+    L = _lib.lib()
+    p = LayerNormParams()
+    y = torch.empty_like(x)
+    if stats is None:
+        stats = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+    p.x, p.x_ld, p.y, p.y_ld = _ptr(x), x.stride(0), _ptr(y), y.stride(0)
+    p.gamma, p.beta, p.stats, p.M, p.C, p.eps = _ptr(gamma), _ptr(beta), _ptr(stats), M, Cc, eps
+    if dy is None:
+        check(L.dd_op_layernorm_fwd(C.byref(p), _stream()), "ln_fwd")
+        return y, stats
+    dx = torch.empty_like(x)
+    p.dy, p.dy_ld, p.dx, p.dx_ld, p.accumulate = _ptr(dy), dy.stride(0), _ptr(dx), dx.stride(0), 0
+    check(L.dd_op_layernorm_bwd(C.byref(p), _stream()), "ln_bwd")
+    return dx
+
+
+def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True):
+    """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors)."""
+    L = _lib.lib()
+    p = AttnParams()
+    o = torch.zeros((B * Nq, H * D), device=q.device, dtype=torch.bfloat16)
+    lse = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    p.B, p.H, p.Nq, p.Nk, p.D, p.scale = B, H, Nq, Nk, D, scale
+    check(L.dd_op_attention_fwd(C.byref(p), _stream()), "attn_fwd")
+    if d_o is None:
+        return o, lse
+    dq = torch.zeros_like(o)
+    dk = torch.zeros((B * Nk, H * D), device=q.device, dtype=torch.bfloat16) if need_dkv else None
+    dv = torch.zeros_like(dk) if need_dkv else None
+    delta = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    p.d_o, p.lddo, p.dq, p.lddq, p.delta = _ptr(d_o), d_o.stride(0), _ptr(dq), dq.stride(0), _ptr(delta)
+    if need_dkv:
+        p.dk, p.dv, p.lddk, p.lddv = _ptr(dk), _ptr(dv), dk.stride(0), dv.stride(0)
+    check(L.dd_op_attention_bwd(C.byref(p), _stream()), "attn_bwd")
+    return o, lse, dq, dk, dv
+
+
+def to_nhwc_bf16(x_nchw, cpad=None):
+    """host/torch-side helper for tests: NCHW fp32 -> [B*H*W, Cpad] bf16 (zero padded)."""
+    B, Cc, H, W = x_nchw.shape
+    cpad = cpad or Cc
+    y = torch.zeros((B, H, W, cpad), dtype=torch.float32)
+    y[..., :Cc] = x_nchw.permute(0, 2, 3, 1)
+    return y.reshape(B * H * W, cpad).to(torch.bfloat16)
+
+
+def from_nhwc(y, B, H, W):
+    return y.float().reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()

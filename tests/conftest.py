@@ -1,0 +1,17 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The HIP library must be present and loadable for every -m gpu test: no silent fallbacks."""
+    from distdiff_amd import _lib
+    return _lib.lib()

@@ -1,0 +1,329 @@
+"""Op-level parity: every hand-written gfx950 kernel family (through the C ABI, include/distdiff_hip_ops.h)
+against a plain torch fp32 CPU computation of the same operation on the same bf16-rounded inputs.
+
+Tolerance statement: inputs/weights are rounded to bf16 on both sides, the kernels accumulate in fp32 and
+round the result to bf16 once, so |err| <= ~2^-8 * |ref| + accumulation noise; checked as
+max|err| <= atol + rtol*max|ref| with the per-test values below.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def assert_close(got, ref, rtol=1.5e-2, atol=1e-3, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite output"
+    err = (got - ref).abs().max().item()
+    lim = atol + rtol * ref.abs().max().item()
+    assert err <= lim, "%s: max err %.4g > %.4g (ref max %.4g)" % (what, err, lim, ref.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    from distdiff_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+CONV_CASES = [
+    # name, B, Cin, Cout, H, W, k, stride, pad, up
+    ("3x3_c64", 2, 64, 128, 16, 16, 3, 1, 1, 0),
+    ("3x3_c320_narrowN", 2, 320, 320, 16, 16, 3, 1, 1, 0),
+    ("3x3_smallcin", 2, 4, 64, 16, 16, 3, 1, 1, 0),
+    ("3x3_cin40_ragged", 1, 40, 72, 9, 7, 3, 1, 1, 0),
+    ("3x3_stride2", 2, 64, 64, 16, 16, 3, 2, 1, 0),
+    ("3x3_up2", 2, 64, 64, 8, 8, 3, 1, 1, 1),
+    ("1x1", 2, 128, 256, 8, 8, 1, 1, 0, 0),
+    ("1x1_stride2", 2, 64, 128, 8, 8, 1, 2, 0, 0),
+    ("7x7_stem", 1, 3, 64, 32, 32, 7, 2, 3, 0),
+    ("3x3_cout3", 1, 128, 3, 16, 16, 3, 1, 1, 0),
+    ("3x3_deepK_splitk", 2, 1280, 128, 8, 8, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_and_dgrad(ops, case):
+    name, B, Cin, Cout, H, W, k, stride, pad, up = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    bias = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    x_req = xin.clone().requires_grad_(True)
+    ref = F.conv2d(x_req, w, bias, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    cin_pad = (Cin + 7) // 8 * 8
+    xd = ops.to_nhwc_bf16(x, cin_pad).cuda()
+    pk = ops.PackedConv(w, pad, mode=0, bias=bias)
+    y = ops.conv_gemm(xd, pk, B, H, W, Ho, Wo, stride=stride, shift=up)
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(y, B, Ho, Wo), ref.detach(), what=name + " fwd")
+    # input-gradient (dgrad): conv of dY with the transposed/flipped weights; stride 2 -> input-dilated gather
+    dy = bf(torch.randn(B, Cout, Ho, Wo, generator=g))
+    (gref,) = torch.autograd.grad(ref, x_req, dy)
+    cout_pad = (Cout + 7) // 8 * 8
+    dyd = ops.to_nhwc_bf16(dy, cout_pad).cuda()
+    pkd = ops.PackedConv(w, pad, mode=1)
+    Hl, Wl = xin.shape[2], xin.shape[3]
+    if stride == 2:
+        dx = ops.conv_gemm(dyd, pkd, B, Ho, Wo, Hl, Wl, stride=1, shift=1, parity=1)
+    else:
+        dx = ops.conv_gemm(dyd, pkd, B, Ho, Wo, Hl, Wl, stride=1)
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(dx, B, Hl, Wl), gref, what=name + " dgrad")
+    if up:  # transpose of the fused nearest-2x: 2x2 sum pooling
+        from distdiff_amd import _lib
+        dxs = torch.empty((B * H * W, dx.shape[1]), device="cuda", dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dd_op_sumpool2x2(C.c_void_p(dx.data_ptr()), dx.stride(0), C.c_void_p(dxs.data_ptr()), dxs.stride(0),
+                                               B, H, W, dx.shape[1], 0, None))
+        torch.cuda.synchronize()
+        xr = x.clone().requires_grad_(True)
+        r2 = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w, bias, stride=stride, padding=pad)
+        (g2,) = torch.autograd.grad(r2, xr, dy)
+        assert_close(ops.from_nhwc(dxs, B, H, W), g2, rtol=2.5e-2, what=name + " dgrad+sumpool")
+
+
+def test_linear_epilogues(ops):
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 300, 320, 640
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    res = bf(torch.randn(M, N, generator=g))
+    xd = x.to(torch.bfloat16).cuda()
+    pk = ops.PackedConv(w, 0, bias=bias)
+    ref = x @ w.t() + bias
+    for ks in (1, 0, 3):
+        y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, ksplit=ks)
+        assert_close(y, ref, what="linear ksplit=%d" % ks)
+    y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, res=res.to(torch.bfloat16).cuda(), ksplit=1)
+    assert_close(y, ref + res, what="linear+res")
+    y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, relu=True, out_f32=True, ksplit=2)
+    assert y.dtype == torch.float32
+    assert_close(y, ref.clamp_min(0), rtol=5e-3, what="linear relu f32 splitk")
+    msk = torch.randn(M, N, generator=g)
+    y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, mask=msk.to(torch.bfloat16).cuda(), ksplit=1)
+    assert_close(y, ref * (bf(msk) > 0), what="linear mask")
+    # strided output / input views (channel concat as a view)
+    big = torch.zeros((M, N + 64), device="cuda", dtype=torch.bfloat16)
+    ops.conv_gemm(xd, pk, 1, M, 1, M, 1, y=big[:, 64:], ksplit=1)
+    assert_close(big[:, 64:], ref, what="linear strided out")
+    assert float(big[:, :64].float().abs().max()) == 0.0
+
+
+def test_geglu_forward_backward(ops):
+    from distdiff_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    M, K, Fd = 200, 128, 256
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(2 * Fd, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(2 * Fd, generator=g) * 0.1
+    pk = ops.PackedConv(w, 0, geglu=True, bias=bias)
+    xd = x.to(torch.bfloat16).cuda()
+    raw = torch.zeros((M, 2 * Fd), device="cuda", dtype=torch.bfloat16)
+    xr = x.clone().requires_grad_(True)
+    proj = xr @ w.t() + bias
+    hid, gate = proj.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    for ks in (1, 2):
+        y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, raw=raw, ksplit=ks)
+        assert_close(y, ref.detach(), rtol=2e-2, what="geglu fwd ks=%d" % ks)
+    dout = bf(torch.randn(M, Fd, generator=g))
+    (gx,) = torch.autograd.grad(ref, xr, dout)
+    draw = torch.zeros_like(raw)
+    dd = dout.to(torch.bfloat16).cuda()
+    _lib.check(_lib.lib().dd_op_geglu_bwd(C.c_void_p(raw.data_ptr()), raw.stride(0), C.c_void_p(dd.data_ptr()), dd.stride(0),
+                                          C.c_void_p(draw.data_ptr()), draw.stride(0), M, Fd, None))
+    pkd = ops.PackedConv(w, 0, mode=1, geglu=True)
+    dx = ops.conv_gemm(draw, pkd, 1, M, 1, M, 1, ksplit=1)
+    assert_close(dx, gx, rtol=3e-2, what="geglu dgrad")
+
+
+@pytest.mark.parametrize("Cc,G,HW,silu,eps", [(320, 32, 256, True, 1e-5), (128, 32, 1024, True, 1e-6), (64, 8, 100, False, 1e-6),
+                                               (2560, 32, 64, True, 1e-5)])
+def test_groupnorm(ops, Cc, G, HW, silu, eps):
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = bf(torch.randn(B, Cc, HW, generator=g) * 2 + 0.5)
+    gamma = torch.randn(Cc, generator=g)
+    beta = torch.randn(Cc, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.group_norm(xr, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    xd = x.permute(0, 2, 1).reshape(B * HW, Cc).to(torch.bfloat16).cuda()
+    y, stats = ops.groupnorm(xd, gamma.cuda(), beta.cuda(), B, HW, G, eps, silu)
+    assert_close(y.float().cpu().reshape(B, HW, Cc).permute(0, 2, 1), ref.detach(), what="gn fwd")
+    dy = bf(torch.randn(B, Cc, HW, generator=g))
+    (gx,) = torch.autograd.grad(ref, xr, dy)
+    dyd = dy.permute(0, 2, 1).reshape(B * HW, Cc).to(torch.bfloat16).cuda()
+    dx = ops.groupnorm(xd, gamma.cuda(), beta.cuda(), B, HW, G, eps, silu, dy=dyd, stats=stats)
+    assert_close(dx.float().cpu().reshape(B, HW, Cc).permute(0, 2, 1), gx, rtol=2e-2, atol=2e-3, what="gn bwd")
+
+
+@pytest.mark.parametrize("Cc", [320, 1280, 64])
+def test_layernorm(ops, Cc):
+    g = torch.Generator().manual_seed(6)
+    M = 77
+    x = bf(torch.randn(M, Cc, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cc,), gamma, beta, 1e-5)
+    xd = x.to(torch.bfloat16).cuda()
+    y, stats = ops.layernorm(xd, gamma.cuda(), beta.cuda(), 1e-5)
+    assert_close(y, ref.detach(), what="ln fwd")
+    dy = bf(torch.randn(M, Cc, generator=g))
+    (gx,) = torch.autograd.grad(ref, xr, dy)
+    dx = ops.layernorm(xd, gamma.cuda(), beta.cuda(), 1e-5, dy=dy.to(torch.bfloat16).cuda(), stats=stats)
+    assert_close(dx, gx, rtol=2e-2, atol=2e-3, what="ln bwd")
+
+
+ATT_CASES = [("self_d40", 2, 8, 256, 256, 40), ("self_d64", 1, 2, 200, 200, 64), ("self_d80", 1, 4, 128, 128, 80),
+             ("self_d160", 1, 2, 64, 64, 160), ("cross77_d40", 2, 8, 256, 77, 40), ("cross77_d160", 1, 8, 64, 77, 160),
+             ("self_d32", 1, 2, 96, 96, 32), ("vae_d512", 1, 1, 256, 256, 512)]
+
+
+@pytest.mark.parametrize("case", ATT_CASES, ids=[c[0] for c in ATT_CASES])
+def test_attention(ops, case):
+    name, B, H, Nq, Nk, D = case
+    g = torch.Generator().manual_seed(7)
+    q = bf(torch.randn(B, Nq, H, D, generator=g))
+    k = bf(torch.randn(B, Nk, H, D, generator=g))
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    # a spiked key row forces the online-softmax rescale path
+    k[0, Nk // 2, 0] *= 6.0
+    scale = 1.0 / math.sqrt(D)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr)
+    d_o = bf(torch.randn(B, Nq, H, D, generator=g))
+    gq, gk, gv = torch.autograd.grad(ref, (qr, kr, vr), d_o)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    cross = Nk == 77
+    out = ops.attention(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale, d_o=dev(d_o, Nq), need_dkv=not cross)
+    o, lse, dq, dk, dv = out
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref.detach(), rtol=2e-2, atol=2e-3, what=name + " O")
+    lse_ref = torch.logsumexp(s.detach(), dim=-1)
+    assert_close(lse, lse_ref, rtol=1e-3, atol=1e-3, what=name + " LSE")
+    assert_close(dq.reshape(B, Nq, H, D), gq, rtol=3e-2, atol=3e-3, what=name + " dQ")
+    if not cross:
+        assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what=name + " dK")
+        assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
+
+
+def test_elementwise_sampler_ops(ops):
+    from distdiff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    B, Cc, H, W = 2, 4, 8, 8
+    HW = H * W
+    P = lambda t: C.c_void_p(t.data_ptr())
+    # CFG + DDIM step and its VJP
+    z = torch.randn(B, Cc, H, W, generator=g)
+    eps2 = torch.randn(2 * B, Cc, H, W, generator=g)
+    coef = torch.tensor([7.5, 0.8, 0.6, 0.9, 0.43589])
+    zr = z.clone().requires_grad_(True)
+    er = eps2.clone().requires_grad_(True)
+    eu, ec = er.chunk(2)
+    eps = eu + coef[0] * (ec - eu)
+    x0 = (zr - coef[2] * eps) / coef[1]
+    zp = coef[3] * x0 + coef[4] * eps
+    eps_nhwc = torch.zeros(2 * B * HW, 8)
+    eps_nhwc[:, :Cc] = eps2.permute(0, 2, 3, 1).reshape(-1, Cc)
+    d_eps, d_z, d_coef = eps_nhwc.cuda(), z.cuda(), coef.cuda()
+    d_zp, d_x0 = torch.empty_like(d_z), torch.empty_like(d_z)
+    _lib.check(L.dd_op_cfg_ddim(P(d_eps), 8, P(d_z), P(d_zp), P(d_x0), B, Cc, HW, P(d_coef), None))
+    assert_close(d_zp, zp.detach(), rtol=1e-5, atol=1e-5, what="ddim z_prev")
+    assert_close(d_x0, x0.detach(), rtol=1e-5, atol=1e-5, what="ddim x0")
+    gx0, gzp = torch.randn(B, Cc, H, W, generator=g), torch.randn(B, Cc, H, W, generator=g)
+    gz_ref, ge_ref = torch.autograd.grad([x0, zp], [zr, er], [gx0, gzp])
+    d_ge = torch.zeros((2 * B * HW, 8), device="cuda", dtype=torch.bfloat16)
+    d_gz = torch.empty_like(d_z)
+    _lib.check(L.dd_op_cfg_ddim_bwd(P(gx0.cuda()), P(gzp.cuda()), P(d_ge), 8, P(d_gz), B, Cc, HW, P(d_coef), None))
+    assert_close(d_gz, gz_ref, rtol=1e-5, atol=1e-5, what="ddim bwd g_z")
+    assert_close(d_ge.float().cpu()[:, :Cc].reshape(2 * B, H, W, Cc).permute(0, 3, 1, 2), ge_ref, rtol=1e-2, what="ddim bwd g_eps")
+    # transform-guidance update
+    e, b = torch.rand(B * Cc, generator=g), torch.randn(B * Cc, generator=g)
+    gg = torch.randn(B, Cc, H, W, generator=g) * 0.01
+    rho, cval = 10.0, 0.2
+    ge = (gg * z).sum((2, 3)).reshape(-1)
+    gb = gg.sum((2, 3)).reshape(-1)
+    en, bn = e - rho * ge, b - rho * gb
+    znew = z * (1 + en.reshape(B, Cc, 1, 1)) + bn.reshape(B, Cc, 1, 1)
+    znew = torch.max(torch.min(znew, z + cval), z - cval)
+    d_out = torch.empty_like(d_z)
+    _lib.check(L.dd_op_transform_update(P(d_z), P(gg.cuda()), P(e.cuda()), P(b.cuda()), P(d_out), B * Cc, HW, rho, cval, None))
+    assert_close(d_out, znew, rtol=1e-5, atol=1e-5, what="transform update")
+
+
+def test_bicubic_maxpool_gap_energy(ops):
+    from distdiff_amd import _lib
+    L = _lib.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(9)
+    B, Hs, Hd = 2, 64, 28   # same 16/7 ratio as 512 -> 224
+    img = bf(torch.randn(B, 3, Hs, Hs, generator=g))
+    ir = img.clone().requires_grad_(True)
+    ref = F.interpolate(ir, size=(Hd, Hd), mode="bicubic")
+    src = ops.to_nhwc_bf16(img, 8).cuda()
+    dst = torch.empty((B * Hd * Hd, 8), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.dd_op_bicubic(P(src), 8, P(dst), 8, B, Hs, Hs, Hd, Hd, 3, 8, None))
+    assert_close(ops.from_nhwc(dst, B, Hd, Hd)[:, :3], ref.detach(), what="bicubic fwd")
+    assert float(dst[:, 3:].float().abs().max()) == 0.0
+    dd = bf(torch.randn(B, 3, Hd, Hd, generator=g))
+    (gi,) = torch.autograd.grad(ref, ir, dd)
+    ddst = ops.to_nhwc_bf16(dd, 8).cuda()
+    dsrc = torch.zeros((B * Hs * Hs, 8), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.dd_op_bicubic_bwd(P(ddst), 8, P(dsrc), 8, B, Hs, Hs, Hd, Hd, 3, None))
+    assert_close(ops.from_nhwc(dsrc, B, Hs, Hs)[:, :3], gi, what="bicubic bwd")
+    # max pool 3x3/2 (+bwd)
+    x = bf(torch.randn(B, 64, 16, 16, generator=g))
+    xr = x.clone().requires_grad_(True)
+    mp = F.max_pool2d(xr, 3, 2, 1)
+    xd = ops.to_nhwc_bf16(x).cuda()
+    yd = torch.empty((B * 8 * 8, 64), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.dd_op_maxpool3x3s2(P(xd), P(yd), B, 16, 16, 64, None))
+    assert_close(ops.from_nhwc(yd, B, 8, 8), mp.detach(), rtol=0, atol=0, what="maxpool")
+    dy = bf(torch.randn(B, 64, 8, 8, generator=g))
+    (gx,) = torch.autograd.grad(mp, xr, dy)
+    dxd = torch.empty_like(xd)
+    _lib.check(L.dd_op_maxpool3x3s2_bwd(P(xd), P(ops.to_nhwc_bf16(dy).cuda()), P(dxd), B, 16, 16, 64, None))
+    assert_close(ops.from_nhwc(dxd, B, 16, 16), gx, rtol=1e-2, what="maxpool bwd")
+    # GAP + energy (+ gradient), both guidance flavours
+    D, K, Ccls = 256, 3, 5
+    feat = bf(torch.randn(B, 7 * 7, D, generator=g).abs())
+    fd = torch.empty((B, D), device="cuda", dtype=torch.float32)
+    _lib.check(L.dd_op_gap(P(feat.reshape(-1, D).to(torch.bfloat16).cuda()), D, P(fd), B, 49, D, None))
+    assert_close(fd, feat.mean(1), rtol=1e-5, atol=1e-5, what="gap")
+    Pc = F.normalize(torch.randn(Ccls, D, generator=g), dim=-1)
+    Pg = F.normalize(torch.randn(Ccls, K, D, generator=g), dim=-1)
+    tg = torch.tensor([3, 1], dtype=torch.int32)
+    for normalize in (0, 1):
+        f = feat.mean(1).clone().requires_grad_(True)
+        fh = f / f.norm(dim=-1, keepdim=True) if normalize else f
+        gp = Pc[tg.long()]
+        sc = torch.norm(fh - gp, dim=1, p=2).mean() * 1.0
+        lp = Pg[tg.long()]
+        idx = torch.argmax(torch.bmm(fh.unsqueeze(1), lp.permute(0, 2, 1)), -1)
+        lp = lp[torch.arange(B), idx.squeeze()]
+        sc = sc + torch.norm(fh - lp, dim=1, p=2).mean() * 0.7
+        sc = sc * 0.5
+        (gf_ref,) = torch.autograd.grad(sc, f)
+        score = torch.zeros(1, device="cuda")
+        gf = torch.empty((B, D), device="cuda")
+        _lib.check(L.dd_op_energy(P(fd), P(Pc.cuda()), P(Pg.cuda()), P(tg.cuda()), B, D, K, 1.0, 0.7, 1, 1, normalize, 0.5,
+                                  P(score), P(gf), None))
+        assert_close(score, sc.detach().reshape(1), rtol=1e-5, atol=1e-6, what="energy score n=%d" % normalize)
+        assert_close(gf, gf_ref, rtol=1e-4, atol=1e-7, what="energy grad n=%d" % normalize)
