@@ -1,0 +1,137 @@
+"""Architecture / sampler configuration of the expansion engine.
+
+Every constant that the reference obtains from the Hugging Face model directory
+(`unet/config.json`, `vae/config.json`, `scheduler/scheduler_config.json`; reference loads them at
+generate_data.py:863-922) lives here with the Stable-Diffusion-v1.x values as defaults, and is
+overridden from those JSON files when a local model directory is given (SURVEY.md section 8a note).
+"""
+import json
+import os
+from dataclasses import asdict, dataclass, field
+from typing import Tuple
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    # SD-1.x: CrossAttnDownBlock2D x3 + DownBlock2D ; UpBlock2D + CrossAttnUpBlock2D x3
+    down_attn: Tuple[bool, ...] = (True, True, True, False)
+    up_attn: Tuple[bool, ...] = (False, True, True, True)
+    num_heads: int = 8                 # diffusers' `attention_head_dim` = 8 is the head COUNT for SD-1.x
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    freq_shift: float = 0.0
+    flip_sin_to_cos: bool = True
+
+    @property
+    def time_embed_dim(self):
+        return self.block_out_channels[0] * 4
+
+
+@dataclass
+class VAEConfig:
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-6
+    scaling_factor: float = 0.18215
+
+
+@dataclass
+class GuideConfig:
+    arch: str = "resnet50"
+    stem_channels: int = 64
+    planes: Tuple[int, ...] = (64, 128, 256, 512)
+    blocks: Tuple[int, ...] = (3, 4, 6, 3)
+    expansion: int = 4
+    bn_eps: float = 1e-5
+    input_size: int = 224              # F.interpolate(..., (224,224), 'bicubic') generate_data.py:704
+
+    @property
+    def feature_dim(self):
+        return self.planes[-1] * self.expansion
+
+
+@dataclass
+class SchedulerConfig:
+    """DDIMScheduler as configured by the SD-1.x repo scheduler_config.json."""
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.00085
+    beta_end: float = 0.012
+    beta_schedule: str = "scaled_linear"
+    steps_offset: int = 1
+    set_alpha_to_one: bool = False
+    clip_sample: bool = False
+    prediction_type: str = "epsilon"
+    timestep_spacing: str = "leading"
+
+
+@dataclass
+class EngineConfig:
+    unet: UNetConfig = field(default_factory=UNetConfig)
+    vae: VAEConfig = field(default_factory=VAEConfig)
+    guide: GuideConfig = field(default_factory=GuideConfig)
+    scheduler: SchedulerConfig = field(default_factory=SchedulerConfig)
+    latent_size: int = 64              # 512 / 8
+    text_len: int = 77
+    max_batch: int = 1                 # train_batch_size (B); the CFG batch is 2B
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def sd15_config(latent_size=64, max_batch=1):
+    return EngineConfig(latent_size=latent_size, max_batch=max_batch)
+
+
+def tiny_config(latent_size=16, max_batch=2):
+    """Small architecture with the same topology (all block types, up/down sampling, cross attention,
+    GEGLU, VAE attention, bottleneck guide) used by the parity tests, golden vectors and smoke()."""
+    return EngineConfig(
+        unet=UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=1, num_heads=2,
+                        cross_attention_dim=64, norm_num_groups=8),
+        vae=VAEConfig(block_out_channels=(32, 64, 64, 64), layers_per_block=1, norm_num_groups=8),
+        guide=GuideConfig(stem_channels=16, planes=(16, 32, 32, 64), blocks=(1, 2, 1, 1), input_size=56),
+        latent_size=latent_size, text_len=13, max_batch=max_batch)
+
+
+def from_model_dir(path, latent_size=64, max_batch=1):
+    """Populates the config from a local HF Stable-Diffusion directory when its JSON files exist."""
+    cfg = sd15_config(latent_size, max_batch)
+
+    def _load(sub):
+        p = os.path.join(path, sub)
+        return json.load(open(p)) if os.path.exists(p) else None
+
+    u = _load("unet/config.json")
+    if u:
+        cfg.unet.block_out_channels = tuple(u.get("block_out_channels", cfg.unet.block_out_channels))
+        cfg.unet.layers_per_block = u.get("layers_per_block", cfg.unet.layers_per_block)
+        cfg.unet.cross_attention_dim = u.get("cross_attention_dim", cfg.unet.cross_attention_dim)
+        cfg.unet.num_heads = u.get("attention_head_dim", cfg.unet.num_heads)
+        cfg.unet.norm_num_groups = u.get("norm_num_groups", cfg.unet.norm_num_groups)
+        cfg.unet.norm_eps = u.get("norm_eps", cfg.unet.norm_eps)
+        cfg.unet.freq_shift = u.get("freq_shift", cfg.unet.freq_shift)
+        cfg.unet.flip_sin_to_cos = u.get("flip_sin_to_cos", cfg.unet.flip_sin_to_cos)
+        if "down_block_types" in u:
+            cfg.unet.down_attn = tuple("CrossAttn" in t for t in u["down_block_types"])
+            cfg.unet.up_attn = tuple("CrossAttn" in t for t in u["up_block_types"])
+    v = _load("vae/config.json")
+    if v:
+        cfg.vae.block_out_channels = tuple(v.get("block_out_channels", cfg.vae.block_out_channels))
+        cfg.vae.layers_per_block = v.get("layers_per_block", cfg.vae.layers_per_block)
+        cfg.vae.scaling_factor = v.get("scaling_factor", cfg.vae.scaling_factor)
+        cfg.vae.norm_num_groups = v.get("norm_num_groups", cfg.vae.norm_num_groups)
+    s = _load("scheduler/scheduler_config.json")
+    if s:
+        for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one",
+                  "clip_sample", "prediction_type", "timestep_spacing"):
+            if k in s:
+                setattr(cfg.scheduler, k, s[k])
+    return cfg

@@ -39,7 +39,7 @@ class PackedConv:
                               wp.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), out4)
         self.w = torch.from_numpy(wp.view(np.int16)).to(device).view(torch.bfloat16)
         self.taptab = torch.from_numpy(tt).to(device)
-        self.geglu = geglu
+        self.geglu = bool(geglu) and mode == 0   # in dgrad form the permutation applies to K only
         self.bias = None
         if bias is not None:
             b = bias.detach().float().cpu()

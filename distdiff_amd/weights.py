@@ -1,0 +1,209 @@
+"""Weight sources for the engine: seeded synthetic weights with the exact Hugging Face / timm key
+names and shapes (there are no checkpoints offline), or real `safetensors` / torch checkpoints from a
+local model directory (same key map, so real SD-1.x / guide weights drop in where they exist).
+
+Key names follow the state dicts the reference loads: diffusers UNet2DConditionModel / AutoencoderKL
+(generate_data.py:912-922) and the timm resnet50 guide checkpoint `{'state_dict': ...}` with an
+optional `module.` prefix (model_utils.py:89-101, train.py:201-207).
+"""
+import hashlib
+import math
+import os
+
+import torch
+
+from .config import EngineConfig
+
+
+def _seed(key, base):
+    return (int(hashlib.md5(key.encode()).hexdigest()[:8], 16) + base) % (2 ** 31)
+
+
+def _randn(key, shape, scale, base_seed):
+    g = torch.Generator().manual_seed(_seed(key, base_seed))
+    return torch.randn(shape, generator=g) * scale
+
+
+class _Builder:
+    def __init__(self, prefix, seed):
+        self.sd = {}
+        self.prefix = prefix
+        self.seed = seed
+
+    def conv(self, name, cout, cin, k, bias=True):
+        self.sd[name + ".weight"] = _randn(self.prefix + name + ".w", (cout, cin, k, k), 1.0 / math.sqrt(cin * k * k), self.seed)
+        if bias:
+            self.sd[name + ".bias"] = _randn(self.prefix + name + ".b", (cout,), 0.02, self.seed)
+
+    def linear(self, name, cout, cin, bias=True):
+        self.sd[name + ".weight"] = _randn(self.prefix + name + ".w", (cout, cin), 1.0 / math.sqrt(cin), self.seed)
+        if bias:
+            self.sd[name + ".bias"] = _randn(self.prefix + name + ".b", (cout,), 0.02, self.seed)
+
+    def norm(self, name, c):
+        self.sd[name + ".weight"] = 1.0 + _randn(self.prefix + name + ".g", (c,), 0.1, self.seed)
+        self.sd[name + ".bias"] = _randn(self.prefix + name + ".b", (c,), 0.1, self.seed)
+
+    def bn(self, name, c):
+        self.norm(name, c)
+        self.sd[name + ".running_mean"] = _randn(self.prefix + name + ".m", (c,), 0.1, self.seed)
+        self.sd[name + ".running_var"] = 1.0 + 0.2 * _randn(self.prefix + name + ".v", (c,), 1.0, self.seed).abs()
+
+
+def unet_resnet_specs(cfg):
+    """Yields (key_prefix, cin, cout) of every UNet ResnetBlock2D in execution order plus structure info."""
+    u = cfg.unet
+    ch = u.block_out_channels
+    specs = {"down": [], "mid": [], "up": []}
+    out = ch[0]
+    for i, c in enumerate(ch):
+        inp, out = out, c
+        specs["down"].append([(inp if j == 0 else out, out) for j in range(u.layers_per_block)])
+    rev = list(reversed(ch))
+    out = rev[0]
+    for i, c in enumerate(rev):
+        prev, out = out, c
+        inp = rev[min(i + 1, len(ch) - 1)]
+        blk = []
+        for j in range(u.layers_per_block + 1):
+            skip = inp if j == u.layers_per_block else out
+            rin = prev if j == 0 else out
+            blk.append((rin + skip, out))
+        specs["up"].append(blk)
+    return specs
+
+
+def synthetic_unet(cfg: EngineConfig, seed=0):
+    u = cfg.unet
+    b = _Builder("unet.", seed)
+    ch = u.block_out_channels
+    temb = u.time_embed_dim
+    b.linear("time_embedding.linear_1", temb, ch[0])
+    b.linear("time_embedding.linear_2", temb, temb)
+    b.conv("conv_in", ch[0], u.in_channels, 3)
+
+    def resnet(p, cin, cout):
+        b.norm(p + ".norm1", cin)
+        b.conv(p + ".conv1", cout, cin, 3)
+        b.linear(p + ".time_emb_proj", cout, temb)
+        b.norm(p + ".norm2", cout)
+        b.conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            b.conv(p + ".conv_shortcut", cout, cin, 1)
+
+    def transformer(p, c):
+        b.norm(p + ".norm", c)
+        b.conv(p + ".proj_in", c, c, 1)
+        t = p + ".transformer_blocks.0"
+        for n in ("norm1", "norm2", "norm3"):
+            b.norm(t + "." + n, c)
+        for a, kv in (("attn1", c), ("attn2", u.cross_attention_dim)):
+            b.linear(t + "." + a + ".to_q", c, c, bias=False)
+            b.linear(t + "." + a + ".to_k", c, kv, bias=False)
+            b.linear(t + "." + a + ".to_v", c, kv, bias=False)
+            b.linear(t + "." + a + ".to_out.0", c, c)
+        b.linear(t + ".ff.net.0.proj", 8 * c, c)
+        b.linear(t + ".ff.net.2", c, 4 * c)
+        b.conv(p + ".proj_out", c, c, 1)
+
+    specs = unet_resnet_specs(cfg)
+    for i, blk in enumerate(specs["down"]):
+        for j, (cin, cout) in enumerate(blk):
+            resnet("down_blocks.%d.resnets.%d" % (i, j), cin, cout)
+            if u.down_attn[i]:
+                transformer("down_blocks.%d.attentions.%d" % (i, j), cout)
+        if i < len(ch) - 1:
+            b.conv("down_blocks.%d.downsamplers.0.conv" % i, ch[i], ch[i], 3)
+    resnet("mid_block.resnets.0", ch[-1], ch[-1])
+    transformer("mid_block.attentions.0", ch[-1])
+    resnet("mid_block.resnets.1", ch[-1], ch[-1])
+    for i, blk in enumerate(specs["up"]):
+        for j, (cin, cout) in enumerate(blk):
+            resnet("up_blocks.%d.resnets.%d" % (i, j), cin, cout)
+            if u.up_attn[i]:
+                transformer("up_blocks.%d.attentions.%d" % (i, j), cout)
+        if i < len(ch) - 1:
+            b.conv("up_blocks.%d.upsamplers.0.conv" % i, blk[-1][1], blk[-1][1], 3)
+    b.norm("conv_norm_out", ch[0])
+    b.conv("conv_out", u.out_channels, ch[0], 3)
+    return b.sd
+
+
+def synthetic_vae_decoder(cfg: EngineConfig, seed=0):
+    v = cfg.vae
+    b = _Builder("vae.", seed)
+    ch = v.block_out_channels
+    top = ch[-1]
+    b.conv("post_quant_conv", v.latent_channels, v.latent_channels, 1)
+    b.conv("decoder.conv_in", top, v.latent_channels, 3)
+
+    def resnet(p, cin, cout):
+        b.norm(p + ".norm1", cin)
+        b.conv(p + ".conv1", cout, cin, 3)
+        b.norm(p + ".norm2", cout)
+        b.conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            b.conv(p + ".conv_shortcut", cout, cin, 1)
+
+    resnet("decoder.mid_block.resnets.0", top, top)
+    a = "decoder.mid_block.attentions.0"
+    b.norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        b.linear(a + "." + n, top, top)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    rev = list(reversed(ch))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(v.layers_per_block + 1):
+            resnet("decoder.up_blocks.%d.resnets.%d" % (i, j), prev if j == 0 else c, c)
+        prev = c
+        if i < len(ch) - 1:
+            b.conv("decoder.up_blocks.%d.upsamplers.0.conv" % i, c, c, 3)
+    b.norm("decoder.conv_norm_out", ch[0])
+    b.conv("decoder.conv_out", v.out_channels, ch[0], 3)
+    return b.sd
+
+
+def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
+    g = cfg.guide
+    b = _Builder("guide.", seed)
+    b.conv("conv1", g.stem_channels, 3, 7, bias=False)
+    b.bn("bn1", g.stem_channels)
+    inp = g.stem_channels
+    for li, (planes, nb) in enumerate(zip(g.planes, g.blocks)):
+        for bi in range(nb):
+            p = "layer%d.%d" % (li + 1, bi)
+            out = planes * g.expansion
+            b.conv(p + ".conv1", planes, inp, 1, bias=False)
+            b.bn(p + ".bn1", planes)
+            b.conv(p + ".conv2", planes, planes, 3, bias=False)
+            b.bn(p + ".bn2", planes)
+            b.conv(p + ".conv3", out, planes, 1, bias=False)
+            b.bn(p + ".bn3", out)
+            if bi == 0 and (inp != out or li > 0):
+                b.conv(p + ".downsample.0", out, inp, 1, bias=False)
+                b.bn(p + ".downsample.1", out)
+            inp = out
+    b.linear("fc", num_classes, inp)
+    return b.sd
+
+
+def synthetic_weights(cfg: EngineConfig, seed=0, num_classes=100):
+    return {"unet": synthetic_unet(cfg, seed), "vae": synthetic_vae_decoder(cfg, seed),
+            "guide": synthetic_guide(cfg, seed, num_classes)}
+
+
+def load_safetensors_dir(model_dir, sub, names=("diffusion_pytorch_model.safetensors",)):
+    from safetensors.torch import load_file
+    for n in names:
+        p = os.path.join(model_dir, sub, n)
+        if os.path.exists(p):
+            return {k: v.float() for k, v in load_file(p).items()}
+    raise FileNotFoundError("no safetensors under %s/%s" % (model_dir, sub))
+
+
+def load_guide_checkpoint(path):
+    """Reference checkpoint format: torch.save({'epoch','state_dict','acc','best_acc','optimizer'}) with an
+    optional DataParallel `module.` prefix (model_utils.py:89-101)."""
+    sd = torch.load(path, map_location="cpu")["state_dict"]
+    return {(k[len("module."):] if k.startswith("module.") else k): v.float() for k, v in sd.items()}

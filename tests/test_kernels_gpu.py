@@ -203,6 +203,7 @@ def test_attention(ops, case):
     v = bf(torch.randn(B, Nk, H, D, generator=g))
     # a spiked key row forces the online-softmax rescale path
     k[0, Nk // 2, 0] *= 6.0
+    k = bf(k)
     scale = 1.0 / math.sqrt(D)
     qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
     s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
@@ -251,7 +252,8 @@ def test_elementwise_sampler_ops(ops):
     gz_ref, ge_ref = torch.autograd.grad([x0, zp], [zr, er], [gx0, gzp])
     d_ge = torch.zeros((2 * B * HW, 8), device="cuda", dtype=torch.bfloat16)
     d_gz = torch.empty_like(d_z)
-    _lib.check(L.dd_op_cfg_ddim_bwd(P(gx0.cuda()), P(gzp.cuda()), P(d_ge), 8, P(d_gz), B, Cc, HW, P(d_coef), None))
+    d_gx0, d_gzp = gx0.cuda(), gzp.cuda()   # keep references alive: the kernels are asynchronous
+    _lib.check(L.dd_op_cfg_ddim_bwd(P(d_gx0), P(d_gzp), P(d_ge), 8, P(d_gz), B, Cc, HW, P(d_coef), None))
     assert_close(d_gz, gz_ref, rtol=1e-5, atol=1e-5, what="ddim bwd g_z")
     assert_close(d_ge.float().cpu()[:, :Cc].reshape(2 * B, H, W, Cc).permute(0, 3, 1, 2), ge_ref, rtol=1e-2, what="ddim bwd g_eps")
     # transform-guidance update
@@ -264,7 +266,8 @@ def test_elementwise_sampler_ops(ops):
     znew = z * (1 + en.reshape(B, Cc, 1, 1)) + bn.reshape(B, Cc, 1, 1)
     znew = torch.max(torch.min(znew, z + cval), z - cval)
     d_out = torch.empty_like(d_z)
-    _lib.check(L.dd_op_transform_update(P(d_z), P(gg.cuda()), P(e.cuda()), P(b.cuda()), P(d_out), B * Cc, HW, rho, cval, None))
+    d_gg, d_e, d_b = gg.cuda(), e.cuda(), b.cuda()
+    _lib.check(L.dd_op_transform_update(P(d_z), P(d_gg), P(d_e), P(d_b), P(d_out), B * Cc, HW, rho, cval, None))
     assert_close(d_out, znew, rtol=1e-5, atol=1e-5, what="transform update")
 
 
@@ -299,13 +302,15 @@ def test_bicubic_maxpool_gap_energy(ops):
     dy = bf(torch.randn(B, 64, 8, 8, generator=g))
     (gx,) = torch.autograd.grad(mp, xr, dy)
     dxd = torch.empty_like(xd)
-    _lib.check(L.dd_op_maxpool3x3s2_bwd(P(xd), P(ops.to_nhwc_bf16(dy).cuda()), P(dxd), B, 16, 16, 64, None))
+    dyd = ops.to_nhwc_bf16(dy).cuda()
+    _lib.check(L.dd_op_maxpool3x3s2_bwd(P(xd), P(dyd), P(dxd), B, 16, 16, 64, None))
     assert_close(ops.from_nhwc(dxd, B, 16, 16), gx, rtol=1e-2, what="maxpool bwd")
     # GAP + energy (+ gradient), both guidance flavours
     D, K, Ccls = 256, 3, 5
     feat = bf(torch.randn(B, 7 * 7, D, generator=g).abs())
     fd = torch.empty((B, D), device="cuda", dtype=torch.float32)
-    _lib.check(L.dd_op_gap(P(feat.reshape(-1, D).to(torch.bfloat16).cuda()), D, P(fd), B, 49, D, None))
+    featd = feat.reshape(-1, D).to(torch.bfloat16).cuda()
+    _lib.check(L.dd_op_gap(P(featd), D, P(fd), B, 49, D, None))
     assert_close(fd, feat.mean(1), rtol=1e-5, atol=1e-5, what="gap")
     Pc = F.normalize(torch.randn(Ccls, D, generator=g), dim=-1)
     Pg = F.normalize(torch.randn(Ccls, K, D, generator=g), dim=-1)
@@ -323,7 +328,9 @@ def test_bicubic_maxpool_gap_energy(ops):
         (gf_ref,) = torch.autograd.grad(sc, f)
         score = torch.zeros(1, device="cuda")
         gf = torch.empty((B, D), device="cuda")
-        _lib.check(L.dd_op_energy(P(fd), P(Pc.cuda()), P(Pg.cuda()), P(tg.cuda()), B, D, K, 1.0, 0.7, 1, 1, normalize, 0.5,
+        dPc, dPg, dtg = Pc.cuda(), Pg.cuda(), tg.cuda()
+        _lib.check(L.dd_op_energy(P(fd), P(dPc), P(dPg), P(dtg), B, D, K, 1.0, 0.7, 1, 1, normalize, 0.5,
                                   P(score), P(gf), None))
+        torch.cuda.synchronize()
         assert_close(score, sc.detach().reshape(1), rtol=1e-5, atol=1e-6, what="energy score n=%d" % normalize)
         assert_close(gf, gf_ref, rtol=1e-4, atol=1e-7, what="energy grad n=%d" % normalize)
