@@ -467,6 +467,24 @@ __global__ void to_uint8_kernel(const float* nchw, uint8_t* hwc, int B, int C, i
   }
 }
 
+// one wave per output element block: y[m, n] = sum_k act(x[m,k]) * W[n,k] + b[n]   (fp32, setup-time only)
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, const float* W, const float* b, float* y, int M, int N, int K,
+                                                         int silu_in) {
+  const int lane = threadIdx.x & 63;
+  const size_t wid = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (wid >= (size_t)M * N) return;
+  const int m = (int)(wid / N), n = (int)(wid % N);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float xv = x[(size_t)m * K + k];
+    if (silu_in) xv = silu_f(xv);
+    s += xv * W[(size_t)n * K + k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[(size_t)m * N + n] = s + (b ? b[n] : 0.f);
+}
+__global__ void scale_rows_kernel(float* x, const float* s, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) x[i] *= s[0]; }
+
 }  // namespace
 
 #define LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, s, __VA_ARGS__); return hipGetLastError()
@@ -555,4 +573,9 @@ hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s) { LAUNCH(fill_kernel, n, dst, v, n); }
 hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s) {
   LAUNCH(to_uint8_kernel, (size_t)B * H * W * C, nchw, hwc, B, C, H * W);
+}
+hipError_t launch_linear_f32(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int silu_in, hipStream_t s) {
+  const size_t waves = (size_t)M * N;
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, W, b, y, M, N, K, silu_in);
+  return hipGetLastError();
 }

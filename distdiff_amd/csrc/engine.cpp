@@ -1,0 +1,1290 @@
+// The expansion engine: a static op-graph executor for the SD-1.x UNet, the AutoencoderKL decoder and the
+// ResNet-50 guide, with a hand-derived reverse program (input-gradients only, no autograd) composed from
+// per-op VJPs, plus the guided DDIM sampler drivers behind the C ABI of include/distdiff_hip.h.
+//
+// Reference functions replaced: generate_data.py:109-121 (denoise_one_step), :687-732 (transform_guidance),
+// :735-767 (direct_guidance), :1161-1228 (loop + decode); diffusers / timm module forwards as listed in
+// SURVEY.md section 8a. Activations are NHWC bf16 matrices; every forward op stashes what its VJP needs
+// (288 GB HBM makes a full stash viable), the reverse program is built once at finalize time.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/distdiff_hip.h"
+#include "kernels.h"
+
+namespace {
+
+#define HIPCHK(x)                                                                                     \
+  do {                                                                                                \
+    hipError_t _e = (x);                                                                              \
+    if (_e != hipSuccess) {                                                                           \
+      char _b[512];                                                                                   \
+      snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      throw std::runtime_error(_b);                                                                   \
+    }                                                                                                 \
+  } while (0)
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+template <class T>
+T* dev_upload(const std::vector<T>& h) {
+  T* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, std::max<size_t>(h.size() * sizeof(T), 16)));
+  if (!h.empty()) HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------------
+struct ConvW {
+  int Cout = 0, Cin = 0, KH = 1, KW = 1, pad = 0;
+  bool geglu = false;
+  PackedConv sf{}, sb{};
+  bf16_t* w_fwd = nullptr; int* tap_fwd = nullptr;
+  bf16_t* w_bwd = nullptr; int* tap_bwd = nullptr;
+  float* bias = nullptr;       // [Cout] (packed order for GEGLU) or null
+  float* bias_table = nullptr; // [n_steps][Cout] per-timestep effective bias (resnet conv1 + time_emb_proj)
+  // fp32 copies kept for the time-embedding tables
+  float* temb_w = nullptr; float* temb_b = nullptr; std::vector<float> conv_bias_host;
+};
+struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+
+// ---------------------------------------------------------------------------------------------------
+// op graph
+// ---------------------------------------------------------------------------------------------------
+struct Tn {              // activation tensor or channel view
+  size_t off = 0;        // byte offset in the activation slab
+  size_t goff = 0;       // byte offset in the gradient slab
+  int parent = -1;       // gradient-tracking parent (self for base tensors)
+  int rows = 0, C = 0, ld = 0, B = 0, H = 0, W = 0;
+  bool f32 = false, grad = false;
+};
+
+enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP };
+
+struct Op {
+  OpKind kind;
+  int x = -1, y = -1, res = -1, raw = -1, q = -1, k = -1, v = -1, x2 = -1;
+  ConvW* cw = nullptr;
+  NormW* nw = nullptr;
+  int stride = 1, up = 0, relu = 0, out_f32 = 0, use_table = 0;
+  int G = 0, silu = 0; float eps = 0;
+  int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
+  size_t stats_off = 0;  // fp32 stats / lse in the activation slab
+  // backward plan
+  bool x_acc = false, res_acc = false, x2_acc = false;
+  double flops = 0;
+};
+
+struct Program {
+  std::vector<Tn> t;
+  std::vector<Op> ops;
+  size_t act_bytes = 0, grad_bytes = 0;
+  size_t scratch_partial = 0, scratch_tmp = 0;  // shared scratch requirements (bytes)
+  bool want_grad = false;
+
+  int tensor(int B, int H, int W, int C, bool grad = true, bool f32 = false) {
+    Tn n;
+    n.B = B; n.H = H; n.W = W; n.rows = B * H * W; n.C = C; n.ld = rup(C, 8); n.f32 = f32;
+    n.grad = grad && want_grad;
+    n.off = act_bytes;
+    act_bytes += rup_sz((size_t)n.rows * n.ld * (f32 ? 4 : 2), 256);
+    if (n.grad) { n.goff = grad_bytes; grad_bytes += rup_sz((size_t)n.rows * n.ld * 2, 256); }
+    n.parent = (int)t.size();
+    t.push_back(n);
+    return (int)t.size() - 1;
+  }
+  int view(int base, int c0, int C) {
+    Tn n = t[base];
+    n.off += (size_t)c0 * 2; n.goff += (size_t)c0 * 2; n.C = C; n.parent = t[base].parent;
+    t.push_back(n);
+    return (int)t.size() - 1;
+  }
+  size_t fp32_block(size_t count) {
+    const size_t o = act_bytes;
+    act_bytes += rup_sz(count * 4, 256);
+    return o;
+  }
+};
+
+struct Ctx {  // per-call execution context
+  char* act = nullptr;   // activation slab of the instance being run
+  char* grad = nullptr;  // shared gradient slab
+  char* scratch_partial = nullptr; size_t partial_cap = 0;
+  char* scratch_tmp = nullptr;
+  float* gn_scratch = nullptr;
+  int step_index = 0;
+  int B = 0;             // live batch of this call (<= built batch)
+  hipStream_t s = nullptr;
+  const std::vector<std::pair<bf16_t*, bf16_t*>>* cross_kv = nullptr;  // per cross-attention slot
+  double* flops = nullptr;
+};
+
+inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
+inline bf16_t* grad_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.grad + t.goff); }
+
+}  // namespace
+
+struct dd_engine {
+  dd_config cfg{};
+  std::string err;
+  std::unordered_map<std::string, HostTensor> raw;  // "model/key" -> fp32 host copy until finalize
+  bool finalized = false;
+
+  std::vector<std::unique_ptr<ConvW>> convs;
+  std::vector<std::unique_ptr<NormW>> norms;
+  std::vector<void*> dev_allocs;
+
+  Program unet, vae, guide;
+  int unet_in = -1, unet_out = -1, vae_in = -1, vae_out = -1, guide_in = -1, guide_feat = -1;
+  struct CrossSlot { ConvW* wk; ConvW* wv; int C; };
+  std::vector<CrossSlot> cross_slots;
+  std::vector<std::pair<bf16_t*, bf16_t*>> cross_kv;  // device K,V [2B*text_len, C] per slot
+  bf16_t* ctx_bf16 = nullptr;                         // [2B*text_len, cross_dim]
+  std::vector<ConvW*> temb_convs;                     // resnet conv1's with time_emb_proj
+  float* temb_w1 = nullptr; float* temb_b1 = nullptr; float* temb_w2 = nullptr; float* temb_b2 = nullptr;
+
+  // schedule
+  std::vector<int> timesteps;
+  float* coef_table = nullptr;   // [n][8]: guidance_scale, sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev), -, -, -
+  dd_sampler_params sp{};
+  // prototypes
+  float* Pc = nullptr; float* Pg = nullptr; int pC = 0, pK = 0, pD = 0;
+
+  // instance slabs: [0 .. P-1]; each holds UNet | VAE | guide activations + small fp32 state
+  struct Inst {
+    char* unet = nullptr; char* vae = nullptr; char* guide = nullptr;
+    float* eps2 = nullptr;  // view into unet slab (conv_out fp32 output)
+    float* z_in = nullptr; float* z_next = nullptr; float* x0 = nullptr; float* feat = nullptr; float* gfeat = nullptr;
+  };
+  std::vector<Inst> inst;
+  char* grad_slab = nullptr;   // shared by the three programs (max of their grad sizes)
+  char* scratch_partial = nullptr; size_t partial_cap = 0;
+  char* scratch_tmp = nullptr; size_t tmp_cap = 0;
+  float* gn_scratch = nullptr;
+  float* f32_tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B,4,L,L] fp32 temporaries
+  float* img_tmp = nullptr;    // [B,3,8L,8L] fp32
+  float* score_tmp = nullptr;
+  size_t total_bytes = 0;
+  double flops = 0;
+
+  void* dmalloc(size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    bytes = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) throw std::runtime_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    if (zero) HIPCHK(hipMemset(p, 0, bytes));
+    dev_allocs.push_back(p);
+    total_bytes += bytes;
+    return p;
+  }
+  const HostTensor& get(const std::string& model, const std::string& key) {
+    auto it = raw.find(model + "/" + key);
+    if (it == raw.end()) throw std::runtime_error("missing weight " + model + "/" + key);
+    return it->second;
+  }
+  bool has(const std::string& model, const std::string& key) { return raw.count(model + "/" + key) != 0; }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// weight construction
+// ---------------------------------------------------------------------------------------------------
+ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, bool geglu,
+                     bool need_bwd) {
+  auto cw = std::make_unique<ConvW>();
+  cw->Cout = Cout; cw->Cin = Cin; cw->KH = KH; cw->KW = KW; cw->pad = pad; cw->geglu = geglu;
+  cw->sf = pack_conv_shape(Cout, Cin, KH, KW, 0);
+  {
+    std::vector<bf16_t> wp((size_t)cw->sf.N * cw->sf.K);
+    std::vector<int> tt(cw->sf.ntaps);
+    pack_conv_weight(w, Cout, Cin, KH, KW, pad, 0, geglu, wp.data(), tt.data());
+    cw->w_fwd = (bf16_t*)E->dmalloc(wp.size() * 2, false);
+    HIPCHK(hipMemcpy(cw->w_fwd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    cw->tap_fwd = (int*)E->dmalloc(tt.size() * 4, false);
+    HIPCHK(hipMemcpy(cw->tap_fwd, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (need_bwd) {
+    cw->sb = pack_conv_shape(Cout, Cin, KH, KW, 1);
+    std::vector<bf16_t> wp((size_t)cw->sb.N * cw->sb.K);
+    std::vector<int> tt(cw->sb.ntaps);
+    pack_conv_weight(w, Cout, Cin, KH, KW, pad, 1, geglu, wp.data(), tt.data());
+    cw->w_bwd = (bf16_t*)E->dmalloc(wp.size() * 2, false);
+    HIPCHK(hipMemcpy(cw->w_bwd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    cw->tap_bwd = (int*)E->dmalloc(tt.size() * 4, false);
+    HIPCHK(hipMemcpy(cw->tap_bwd, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (bias) {
+    std::vector<float> b(Cout);
+    for (int n = 0; n < Cout; ++n) b[n] = bias[geglu ? geglu_perm(n, Cout / 2) : n];
+    cw->bias = (float*)E->dmalloc(Cout * 4, false);
+    HIPCHK(hipMemcpy(cw->bias, b.data(), Cout * 4, hipMemcpyHostToDevice));
+    cw->conv_bias_host.assign(bias, bias + Cout);
+  }
+  E->convs.push_back(std::move(cw));
+  return E->convs.back().get();
+}
+
+ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& prefix, int pad, bool geglu = false,
+                 bool has_bias = true) {
+  const HostTensor& w = E->get(model, prefix + ".weight");
+  const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+  const int KH = w.shape.size() == 4 ? (int)w.shape[2] : 1, KW = w.shape.size() == 4 ? (int)w.shape[3] : 1;
+  const float* b = nullptr;
+  if (has_bias && E->has(model, prefix + ".bias")) b = E->get(model, prefix + ".bias").data.data();
+  return make_conv_raw(E, w.data.data(), b, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0);
+}
+
+// several linears sharing the input, concatenated along Cout (fused QKV)
+ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias) {
+  std::vector<float> w, b;
+  int Cin = 0, Cout = 0;
+  for (auto& p : prefixes) {
+    const HostTensor& t = E->get(model, p + ".weight");
+    Cin = (int)t.shape[1];
+    Cout += (int)t.shape[0];
+    w.insert(w.end(), t.data.begin(), t.data.end());
+    if (with_bias) { const HostTensor& bb = E->get(model, p + ".bias"); b.insert(b.end(), bb.data.begin(), bb.data.end()); }
+  }
+  return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0);
+}
+
+// conv (no bias) followed by eval-mode BatchNorm, folded: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)
+ConvW* make_conv_bn(dd_engine* E, const std::string& model, const std::string& conv, const std::string& bn, int pad, float eps) {
+  const HostTensor& w = E->get(model, conv + ".weight");
+  const HostTensor& g = E->get(model, bn + ".weight");
+  const HostTensor& be = E->get(model, bn + ".bias");
+  const HostTensor& mu = E->get(model, bn + ".running_mean");
+  const HostTensor& var = E->get(model, bn + ".running_var");
+  const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3];
+  std::vector<float> wf(w.data.size()), bf(Cout);
+  const size_t per = (size_t)Cin * KH * KW;
+  for (int n = 0; n < Cout; ++n) {
+    const float sc = g.data[n] / sqrtf(var.data[n] + eps);
+    for (size_t i = 0; i < per; ++i) wf[n * per + i] = w.data[n * per + i] * sc;
+    bf[n] = be.data[n] - mu.data[n] * sc;
+  }
+  return make_conv_raw(E, wf.data(), bf.data(), Cout, Cin, KH, KW, pad, false, E->cfg.enable_grad != 0);
+}
+
+NormW* make_norm(dd_engine* E, const std::string& model, const std::string& prefix) {
+  auto nw = std::make_unique<NormW>();
+  const HostTensor& g = E->get(model, prefix + ".weight");
+  const HostTensor& b = E->get(model, prefix + ".bias");
+  nw->C = (int)g.shape[0];
+  nw->gamma = (float*)E->dmalloc(nw->C * 4, false);
+  nw->beta = (float*)E->dmalloc(nw->C * 4, false);
+  HIPCHK(hipMemcpy(nw->gamma, g.data.data(), nw->C * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(nw->beta, b.data.data(), nw->C * 4, hipMemcpyHostToDevice));
+  E->norms.push_back(std::move(nw));
+  return E->norms.back().get();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// program builder helpers
+// ---------------------------------------------------------------------------------------------------
+struct Builder {
+  dd_engine* E;
+  Program& P;
+  Builder(dd_engine* e, Program& p) : E(e), P(p) {}
+
+  // y = epilogue(conv(x)) ; returns y (allocated unless `y_into` >= 0)
+  int conv(int x, ConvW* w, int stride = 1, int up = 0, int res = -1, int relu = 0, int out_f32 = 0, int use_table = 0,
+           int y_into = -1, bool keep_raw = true) {
+    const Tn& tx = P.t[x];
+    const int Hl = tx.H << up, Wl = tx.W << up;
+    const int Ho = (Hl + 2 * w->pad - w->KH) / stride + 1, Wo = (Wl + 2 * w->pad - w->KW) / stride + 1;
+    const int Cy = w->geglu ? w->Cout / 2 : w->Cout;
+    int y = y_into >= 0 ? y_into : P.tensor(tx.B, Ho, Wo, Cy, true, out_f32 != 0);
+    Op op; op.kind = OP_CONV; op.x = x; op.y = y; op.res = res; op.cw = w; op.stride = stride; op.up = up; op.relu = relu;
+    op.out_f32 = out_f32; op.use_table = use_table;
+    if (w->geglu && P.want_grad && keep_raw) op.raw = P.tensor(tx.B, Ho, Wo, w->Cout, false);
+    const size_t M = (size_t)tx.B * Ho * Wo;
+    op.flops = 2.0 * M * w->Cout * w->Cin * w->KH * w->KW;
+    const int split = conv_gemm_pick_split((int)M, w->sf.N, w->sf.K);
+    P.scratch_partial = std::max(P.scratch_partial, (size_t)split * M * w->sf.N * 4);
+    if (P.want_grad) {
+      const size_t Mb = (size_t)tx.B * Hl * Wl;  // dgrad output rows (high-res when upsample is fused)
+      const int sb = conv_gemm_pick_split((int)Mb, w->sb.N, w->sb.K);
+      P.scratch_partial = std::max(P.scratch_partial, (size_t)sb * Mb * w->sb.N * 4);
+      size_t tmp = 0;
+      if (up) tmp += rup_sz(Mb * rup(w->Cin, 8) * 2, 256);
+      if (w->geglu) tmp += rup_sz(M * w->Cout * 2, 256);
+      P.scratch_tmp = std::max(P.scratch_tmp, tmp);
+    }
+    P.ops.push_back(op);
+    return y;
+  }
+  int gn(int x, NormW* w, int G, float eps, int silu) {
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    Op op; op.kind = OP_GN; op.x = x; op.y = y; op.nw = w; op.G = G; op.eps = eps; op.silu = silu;
+    op.stats_off = P.fp32_block((size_t)tx.B * G * 2);
+    P.ops.push_back(op);
+    return y;
+  }
+  int ln(int x, NormW* w, float eps) {
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    Op op; op.kind = OP_LN; op.x = x; op.y = y; op.nw = w; op.eps = eps;
+    op.stats_off = P.fp32_block((size_t)tx.rows * 2);
+    P.ops.push_back(op);
+    return y;
+  }
+  // self attention: q,k,v are views ; cross attention: k,v come from slot (constant, no grad)
+  int attn(int q, int k, int v, int heads, int Nq, int Nk, int cross_slot) {
+    const Tn& tq = P.t[q];
+    int y = P.tensor(tq.B, tq.H, tq.W, tq.C);
+    Op op; op.kind = OP_ATTN; op.q = q; op.k = k; op.v = v; op.y = y; op.heads = heads; op.D = tq.C / heads; op.Nq = Nq; op.Nk = Nk;
+    op.cross_slot = cross_slot;
+    op.stats_off = P.fp32_block((size_t)tq.B * heads * Nq * 2);  // lse + delta
+    op.flops = 4.0 * tq.B * heads * (double)Nq * Nk * op.D;
+    P.ops.push_back(op);
+    return y;
+  }
+  int concat(int a, int b) {
+    const Tn& ta = P.t[a]; const Tn& tb = P.t[b];
+    int y = P.tensor(ta.B, ta.H, ta.W, ta.C + tb.C);
+    Op op; op.kind = OP_CONCAT; op.x = a; op.x2 = b; op.y = y;
+    P.ops.push_back(op);
+    return y;
+  }
+  int maxpool(int x) {
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, tx.H / 2, tx.W / 2, tx.C);
+    Op op; op.kind = OP_MAXPOOL; op.x = x; op.y = y;
+    P.ops.push_back(op);
+    return y;
+  }
+};
+
+// decide, for every op input, whether its gradient contribution is the first write (assign) or an accumulation
+void plan_backward(Program& P) {
+  std::vector<int> state(P.t.size(), 0);       // per parent: 0 none, 1 partial (views), 2 full
+  std::vector<char> vwritten(P.t.size(), 0);   // per view
+  auto mark = [&](int id) -> bool {            // returns accumulate?
+    const Tn& t = P.t[id];
+    if (!t.grad) return false;
+    const bool is_view = (t.parent != id);
+    if (!is_view) {
+      if (state[id] == 1) throw std::runtime_error("backward plan: whole-tensor gradient write after a partial view write");
+      const bool acc = state[id] == 2;
+      state[id] = 2;
+      return acc;
+    }
+    if (state[t.parent] == 2 || vwritten[id]) return true;
+    vwritten[id] = 1;
+    state[t.parent] = 1;
+    return false;
+  };
+  for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
+    Op& op = P.ops[i];
+    switch (op.kind) {
+      case OP_CONV:
+        if (op.res >= 0) op.res_acc = mark(op.res);
+        op.x_acc = mark(op.x);
+        break;
+      case OP_GN: case OP_LN: case OP_MAXPOOL: case OP_GAP:
+        op.x_acc = mark(op.x);
+        break;
+      case OP_ATTN:
+        mark(op.q);
+        if (op.cross_slot < 0) { mark(op.k); mark(op.v); }
+        break;
+      case OP_CONCAT:
+        op.x_acc = mark(op.x);
+        op.x2_acc = mark(op.x2);
+        break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------------
+void fill_conv(ConvGemmParams& p, const Ctx& c) {
+  memset(&p, 0, sizeof p);
+  p.partial = (float*)c.scratch_partial;
+  p.alpha = 1.f;
+}
+
+void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) {
+  if (op_end < 0) op_end = (int)P.ops.size();
+  for (int i = op_begin; i < op_end; ++i) {
+    const Op& op = P.ops[i];
+    switch (op.kind) {
+      case OP_CONV: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        ConvGemmParams p; fill_conv(p, c);
+        const ConvW* w = op.cw;
+        p.x = act_ptr(c, x); p.x_ld = x.ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
+        p.y = c.act + y.off; p.y_ld = y.ld;
+        p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.shift = op.up; p.parity = 0;
+        p.cin = w->sf.cin; p.ntaps = w->sf.ntaps; p.M = y.rows; p.N = w->sf.N; p.K = w->sf.K;
+        int flags = 0;
+        if (op.use_table && w->bias_table) { flags |= CF_BIAS; p.bias = w->bias_table + (size_t)c.step_index * w->Cout; }
+        else if (w->bias) { flags |= CF_BIAS; p.bias = w->bias; }
+        if (op.res >= 0) { flags |= CF_RES; p.res = act_ptr(c, P.t[op.res]); p.res_ld = P.t[op.res].ld; }
+        if (op.relu) flags |= CF_RELU;
+        if (op.out_f32) flags |= CF_OUT_F32;
+        if (w->geglu) {
+          flags |= CF_GEGLU;
+          if (op.raw >= 0) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
+        }
+        p.flags = flags;
+        HIPCHK(launch_conv_gemm(p, c.partial_cap, c.s));
+        if (c.flops) *c.flops += op.flops;
+      } break;
+      case OP_GN: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        GroupNormParams p; memset(&p, 0, sizeof p);
+        p.x = act_ptr(c, x); p.x_ld = x.ld; p.y = act_ptr(c, y); p.y_ld = y.ld;
+        p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off); p.scratch = c.gn_scratch;
+        p.B = x.B; p.HW = x.H * x.W; p.C = x.C; p.G = op.G; p.eps = op.eps; p.silu = op.silu;
+        HIPCHK(launch_groupnorm_fwd(p, c.s));
+      } break;
+      case OP_LN: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        LayerNormParams p; memset(&p, 0, sizeof p);
+        p.x = act_ptr(c, x); p.x_ld = x.ld; p.y = act_ptr(c, y); p.y_ld = y.ld;
+        p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off);
+        p.M = x.rows; p.C = x.C; p.eps = op.eps;
+        HIPCHK(launch_layernorm_fwd(p, c.s));
+      } break;
+      case OP_ATTN: {
+        const Tn& q = P.t[op.q]; const Tn& y = P.t[op.y];
+        AttnParams p; memset(&p, 0, sizeof p);
+        p.q = act_ptr(c, q); p.ldq = q.ld;
+        if (op.cross_slot >= 0) {
+          p.k = (*c.cross_kv)[op.cross_slot].first; p.v = (*c.cross_kv)[op.cross_slot].second; p.ldk = p.ldv = q.C;
+        } else {
+          p.k = act_ptr(c, P.t[op.k]); p.v = act_ptr(c, P.t[op.v]); p.ldk = P.t[op.k].ld; p.ldv = P.t[op.v].ld;
+        }
+        p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
+        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
+        HIPCHK(launch_attention_fwd(p, c.s));
+        if (c.flops) *c.flops += op.flops;
+      } break;
+      case OP_CONCAT: {
+        const Tn& a = P.t[op.x]; const Tn& b = P.t[op.x2]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_copy_bf16(act_ptr(c, a), a.ld, act_ptr(c, y), y.ld, y.rows, a.C, c.s));
+        HIPCHK(launch_copy_bf16(act_ptr(c, b), b.ld, act_ptr(c, y) + a.C, y.ld, y.rows, b.C, c.s));
+      } break;
+      case OP_MAXPOOL: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_maxpool3x3s2(act_ptr(c, x), act_ptr(c, y), x.B, x.H, x.W, x.C, c.s));
+      } break;
+      case OP_GAP: break;
+    }
+  }
+}
+
+void run_bwd(const Program& P, const Ctx& c) {
+  for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
+    const Op& op = P.ops[i];
+    switch (op.kind) {
+      case OP_CONV: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad && !(op.res >= 0 && P.t[op.res].grad)) break;
+        bf16_t* gy = grad_ptr(c, y);
+        const ConvW* w = op.cw;
+        if (op.relu) HIPCHK(launch_mask_bf16(gy, y.ld, act_ptr(c, y), y.ld, gy, y.ld, y.rows, y.C, c.s));
+        if (op.res >= 0 && P.t[op.res].grad) {
+          const Tn& r = P.t[op.res];
+          if (op.res_acc) HIPCHK(launch_add_bf16(grad_ptr(c, r), r.ld, gy, y.ld, grad_ptr(c, r), r.ld, r.rows, r.C, c.s));
+          else HIPCHK(launch_copy_bf16(gy, y.ld, grad_ptr(c, r), r.ld, r.rows, r.C, c.s));
+        }
+        if (!x.grad) break;
+        const bf16_t* gin = gy; int gin_ld = y.ld;
+        char* tmp = c.scratch_tmp;
+        if (w->geglu) {
+          bf16_t* draw = (bf16_t*)tmp; tmp += rup_sz((size_t)y.rows * w->Cout * 2, 256);
+          HIPCHK(launch_geglu_bwd(act_ptr(c, P.t[op.raw]), P.t[op.raw].ld, gy, y.ld, draw, w->Cout, y.rows, w->Cout / 2, c.s));
+          gin = draw; gin_ld = w->Cout;
+        }
+        ConvGemmParams p; fill_conv(p, c);
+        p.x = gin; p.x_ld = gin_ld; p.w = w->w_bwd; p.taptab = w->tap_bwd;
+        p.B = y.B; p.H = y.H; p.W = y.W;
+        p.cin = w->sb.cin; p.ntaps = w->sb.ntaps; p.N = w->sb.N; p.K = w->sb.K;
+        p.stride = 1;
+        if (op.stride == 2) { p.shift = 1; p.parity = 1; }
+        const int Hl = x.H << op.up, Wl = x.W << op.up;
+        p.Ho = Hl; p.Wo = Wl; p.M = x.B * Hl * Wl;
+        bf16_t* gx = grad_ptr(c, x);
+        if (op.up) {
+          bf16_t* hi = (bf16_t*)tmp;
+          const int ldh = rup(w->Cin, 8);
+          p.y = hi; p.y_ld = ldh; p.flags = 0;
+          HIPCHK(launch_conv_gemm(p, c.partial_cap, c.s));
+          HIPCHK(launch_sumpool2x2(hi, ldh, gx, x.ld, x.B, x.H, x.W, rup(x.C, 8), op.x_acc ? 1 : 0, c.s));
+        } else {
+          p.y = gx; p.y_ld = x.ld; p.flags = 0;
+          if (op.x_acc) { p.flags |= CF_RES; p.res = gx; p.res_ld = x.ld; }
+          HIPCHK(launch_conv_gemm(p, c.partial_cap, c.s));
+        }
+        if (c.flops) *c.flops += op.flops;
+      } break;
+      case OP_GN: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        GroupNormParams p; memset(&p, 0, sizeof p);
+        p.x = act_ptr(c, x); p.x_ld = x.ld;
+        p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off); p.scratch = c.gn_scratch;
+        p.B = x.B; p.HW = x.H * x.W; p.C = x.C; p.G = op.G; p.eps = op.eps; p.silu = op.silu;
+        p.dy = grad_ptr(c, y); p.dy_ld = y.ld; p.dx = grad_ptr(c, x); p.dx_ld = x.ld; p.accumulate = op.x_acc;
+        HIPCHK(launch_groupnorm_bwd(p, c.s));
+      } break;
+      case OP_LN: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        LayerNormParams p; memset(&p, 0, sizeof p);
+        p.x = act_ptr(c, x); p.x_ld = x.ld; p.gamma = op.nw->gamma; p.beta = op.nw->beta;
+        p.stats = (float*)(c.act + op.stats_off); p.M = x.rows; p.C = x.C; p.eps = op.eps;
+        p.dy = grad_ptr(c, y); p.dy_ld = y.ld; p.dx = grad_ptr(c, x); p.dx_ld = x.ld; p.accumulate = op.x_acc;
+        HIPCHK(launch_layernorm_bwd(p, c.s));
+      } break;
+      case OP_ATTN: {
+        const Tn& q = P.t[op.q]; const Tn& y = P.t[op.y];
+        if (!q.grad) break;
+        AttnParams p; memset(&p, 0, sizeof p);
+        p.q = act_ptr(c, q); p.ldq = q.ld;
+        if (op.cross_slot >= 0) {
+          p.k = (*c.cross_kv)[op.cross_slot].first; p.v = (*c.cross_kv)[op.cross_slot].second; p.ldk = p.ldv = q.C;
+        } else {
+          const Tn& k = P.t[op.k]; const Tn& v = P.t[op.v];
+          p.k = act_ptr(c, k); p.v = act_ptr(c, v); p.ldk = k.ld; p.ldv = v.ld;
+          p.dk = grad_ptr(c, k); p.dv = grad_ptr(c, v); p.lddk = k.ld; p.lddv = v.ld;
+        }
+        p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
+        p.delta = p.lse + (size_t)q.B * op.heads * op.Nq;
+        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
+        p.d_o = grad_ptr(c, y); p.lddo = y.ld; p.dq = grad_ptr(c, q); p.lddq = q.ld;
+        HIPCHK(launch_attention_bwd(p, c.s));
+        if (c.flops) *c.flops += op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5);
+      } break;
+      case OP_CONCAT: {
+        const Tn& a = P.t[op.x]; const Tn& b = P.t[op.x2]; const Tn& y = P.t[op.y];
+        bf16_t* gy = grad_ptr(c, y);
+        if (a.grad) {
+          if (op.x_acc) HIPCHK(launch_add_bf16(grad_ptr(c, a), a.ld, gy, y.ld, grad_ptr(c, a), a.ld, a.rows, a.C, c.s));
+          else HIPCHK(launch_copy_bf16(gy, y.ld, grad_ptr(c, a), a.ld, a.rows, a.C, c.s));
+        }
+        if (b.grad) {
+          if (op.x2_acc) HIPCHK(launch_add_bf16(grad_ptr(c, b), b.ld, gy + a.C, y.ld, grad_ptr(c, b), b.ld, b.rows, b.C, c.s));
+          else HIPCHK(launch_copy_bf16(gy + a.C, y.ld, grad_ptr(c, b), b.ld, b.rows, b.C, c.s));
+        }
+      } break;
+      case OP_MAXPOOL: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        if (op.x_acc) throw std::runtime_error("maxpool backward accumulate unsupported");
+        HIPCHK(launch_maxpool3x3s2_bwd(act_ptr(c, x), grad_ptr(c, y), grad_ptr(c, x), x.B, x.H, x.W, x.C, c.s));
+      } break;
+      case OP_GAP: break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// model builders (topology: SURVEY.md section 8a rows A2, A4, A7)
+// ---------------------------------------------------------------------------------------------------
+int build_resnet(Builder& b, const std::string& model, const std::string& p, int x, int G, float eps, bool temb) {
+  dd_engine* E = b.E;
+  NormW* n1 = make_norm(E, model, p + ".norm1");
+  ConvW* c1 = make_conv(E, model, p + ".conv1", 1);
+  NormW* n2 = make_norm(E, model, p + ".norm2");
+  ConvW* c2 = make_conv(E, model, p + ".conv2", 1);
+  if (temb) {
+    // per-timestep effective bias table is filled by dd_set_schedule from time_emb_proj
+    const HostTensor& tw = E->get(model, p + ".time_emb_proj.weight");
+    const HostTensor& tb = E->get(model, p + ".time_emb_proj.bias");
+    c1->temb_w = (float*)E->dmalloc(tw.data.size() * 4, false);
+    c1->temb_b = (float*)E->dmalloc(tb.data.size() * 4, false);
+    HIPCHK(hipMemcpy(c1->temb_w, tw.data.data(), tw.data.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c1->temb_b, tb.data.data(), tb.data.size() * 4, hipMemcpyHostToDevice));
+    E->temb_convs.push_back(c1);
+  }
+  int h = b.gn(x, n1, G, eps, 1);
+  h = b.conv(h, c1, 1, 0, -1, 0, 0, temb ? 1 : 0);
+  h = b.gn(h, n2, G, eps, 1);
+  int sc = x;
+  if (E->has(model, p + ".conv_shortcut.weight")) sc = b.conv(x, make_conv(E, model, p + ".conv_shortcut", 0));
+  return b.conv(h, c2, 1, 0, sc);
+}
+
+int build_transformer(Builder& b, const std::string& p, int x, int heads, int G) {
+  dd_engine* E = b.E;
+  Program& P = b.P;
+  const std::string m = "unet";
+  const int C = P.t[x].C, HW = P.t[x].H * P.t[x].W;
+  int h = b.gn(x, make_norm(E, m, p + ".norm"), G, 1e-6f, 0);
+  h = b.conv(h, make_conv(E, m, p + ".proj_in", 0));
+  const std::string t = p + ".transformer_blocks.0";
+  // self attention (fused QKV projection, no bias)
+  int n = b.ln(h, make_norm(E, m, t + ".norm1"), 1e-5f);
+  int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false));
+  int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+  int a = b.attn(q, k, v, heads, HW, HW, -1);
+  h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
+  // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
+  n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
+  int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false));
+  dd_engine::CrossSlot slot;
+  slot.wk = make_conv(E, m, t + ".attn2.to_k", 0, false, false);
+  slot.wv = make_conv(E, m, t + ".attn2.to_v", 0, false, false);
+  slot.C = C;
+  E->cross_slots.push_back(slot);
+  a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1);
+  h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
+  // GEGLU feed-forward
+  n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);
+  int ff = b.conv(n, make_conv(E, m, t + ".ff.net.0.proj", 0, true));
+  h = b.conv(ff, make_conv(E, m, t + ".ff.net.2", 0), 1, 0, h);
+  return b.conv(h, make_conv(E, m, p + ".proj_out", 0), 1, 0, x);
+}
+
+void build_unet(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->unet;
+  P.want_grad = c.enable_grad != 0;
+  Builder b(E, P);
+  const int B2 = 2 * c.max_batch, L = c.latent_size, G = c.unet_groups, nl = c.unet_levels;
+  const float eps = c.unet_eps;
+  const std::string m = "unet";
+  E->unet_in = P.tensor(B2, L, L, c.unet_in_channels);
+  int h = b.conv(E->unet_in, make_conv(E, m, "conv_in", 1));
+  std::vector<int> skips{h};
+  char buf[128];
+  for (int i = 0; i < nl; ++i) {
+    for (int j = 0; j < c.unet_layers_per_block; ++j) {
+      snprintf(buf, sizeof buf, "down_blocks.%d.resnets.%d", i, j);
+      h = build_resnet(b, m, buf, h, G, eps, true);
+      if (c.unet_down_attn[i]) { snprintf(buf, sizeof buf, "down_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, c.unet_num_heads, G); }
+      skips.push_back(h);
+    }
+    if (i < nl - 1) {
+      snprintf(buf, sizeof buf, "down_blocks.%d.downsamplers.0.conv", i);
+      h = b.conv(h, make_conv(E, m, buf, 1), 2);
+      skips.push_back(h);
+    }
+  }
+  h = build_resnet(b, m, "mid_block.resnets.0", h, G, eps, true);
+  h = build_transformer(b, "mid_block.attentions.0", h, c.unet_num_heads, G);
+  h = build_resnet(b, m, "mid_block.resnets.1", h, G, eps, true);
+  for (int i = 0; i < nl; ++i) {
+    for (int j = 0; j < c.unet_layers_per_block + 1; ++j) {
+      h = b.concat(h, skips.back()); skips.pop_back();
+      snprintf(buf, sizeof buf, "up_blocks.%d.resnets.%d", i, j);
+      h = build_resnet(b, m, buf, h, G, eps, true);
+      if (c.unet_up_attn[i]) { snprintf(buf, sizeof buf, "up_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, c.unet_num_heads, G); }
+    }
+    if (i < nl - 1) {
+      snprintf(buf, sizeof buf, "up_blocks.%d.upsamplers.0.conv", i);
+      h = b.conv(h, make_conv(E, m, buf, 1), 1, 1);
+    }
+  }
+  h = b.gn(h, make_norm(E, m, "conv_norm_out"), G, eps, 1);
+  E->unet_out = b.conv(h, make_conv(E, m, "conv_out", 1), 1, 0, -1, 0, 1);
+  if (P.want_grad) plan_backward(P);
+}
+
+void build_vae(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->vae;
+  P.want_grad = c.enable_grad != 0;
+  Builder b(E, P);
+  const int B = c.max_batch, L = c.latent_size, G = c.vae_groups, nl = c.vae_levels;
+  const float eps = c.vae_eps;
+  const std::string m = "vae";
+  E->vae_in = P.tensor(B, L, L, c.vae_latent_channels);
+  int h = b.conv(E->vae_in, make_conv(E, m, "post_quant_conv", 0));
+  h = b.conv(h, make_conv(E, m, "decoder.conv_in", 1));
+  h = build_resnet(b, m, "decoder.mid_block.resnets.0", h, G, eps, false);
+  {
+    const std::string a = "decoder.mid_block.attentions.0";
+    const int C = P.t[h].C, HW = P.t[h].H * P.t[h].W;
+    int n = b.gn(h, make_norm(E, m, a + ".group_norm"), G, eps, 0);
+    int qkv = b.conv(n, make_conv_cat(E, m, {a + ".to_q", a + ".to_k", a + ".to_v"}, true));
+    int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+    int o = b.attn(q, k, v, 1, HW, HW, -1);
+    h = b.conv(o, make_conv(E, m, a + ".to_out.0", 0), 1, 0, h);
+  }
+  h = build_resnet(b, m, "decoder.mid_block.resnets.1", h, G, eps, false);
+  char buf[128];
+  for (int i = 0; i < nl; ++i) {
+    for (int j = 0; j < c.vae_layers_per_block + 1; ++j) {
+      snprintf(buf, sizeof buf, "decoder.up_blocks.%d.resnets.%d", i, j);
+      h = build_resnet(b, m, buf, h, G, eps, false);
+    }
+    if (i < nl - 1) {
+      snprintf(buf, sizeof buf, "decoder.up_blocks.%d.upsamplers.0.conv", i);
+      h = b.conv(h, make_conv(E, m, buf, 1), 1, 1);
+    }
+  }
+  h = b.gn(h, make_norm(E, m, "decoder.conv_norm_out"), G, eps, 1);
+  E->vae_out = b.conv(h, make_conv(E, m, "decoder.conv_out", 1));
+  if (P.want_grad) plan_backward(P);
+}
+
+void build_guide(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->guide;
+  P.want_grad = c.enable_grad != 0;
+  Builder b(E, P);
+  const std::string m = "guide";
+  const int B = c.max_batch, S = c.guide_input_size;
+  const float eps = c.guide_bn_eps;
+  E->guide_in = P.tensor(B, S, S, 3);
+  int h = b.conv(E->guide_in, make_conv_bn(E, m, "conv1", "bn1", 3, eps), 2, 0, -1, 1);
+  h = b.maxpool(h);
+  char buf[128], bn[128];
+  for (int li = 0; li < c.guide_stages; ++li)
+    for (int bi = 0; bi < c.guide_blocks[li]; ++bi) {
+      const int stride = (bi == 0 && li > 0) ? 2 : 1;
+      snprintf(buf, sizeof buf, "layer%d.%d", li + 1, bi);
+      const std::string p = buf;
+      int o = b.conv(h, make_conv_bn(E, m, p + ".conv1", p + ".bn1", 0, eps), 1, 0, -1, 1);
+      o = b.conv(o, make_conv_bn(E, m, p + ".conv2", p + ".bn2", 1, eps), stride, 0, -1, 1);
+      int sc = h;
+      if (E->has(m, p + ".downsample.0.weight")) sc = b.conv(h, make_conv_bn(E, m, p + ".downsample.0", p + ".downsample.1", 0, eps), stride);
+      h = b.conv(o, make_conv_bn(E, m, p + ".conv3", p + ".bn3", 0, eps), 1, 0, sc, 1);
+      (void)bn;
+    }
+  E->guide_feat = h;
+  if (P.want_grad) plan_backward(P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sampler drivers
+// ---------------------------------------------------------------------------------------------------
+struct Run {
+  dd_engine* E; hipStream_t s; int B;
+  Ctx ctx(const Program&, char* act) {
+    Ctx c; c.act = act; c.grad = E->grad_slab; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
+    c.scratch_tmp = E->scratch_tmp; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops;
+    return c;
+  }
+};
+
+void check_batch(dd_engine* E, int B) {
+  if (B != E->cfg.max_batch) throw std::runtime_error("this engine was built for batch " + std::to_string(E->cfg.max_batch) +
+                                                      " (static shapes); got B=" + std::to_string(B));
+  if (!E->finalized) throw std::runtime_error("dd_finalize_weights has not been called");
+}
+
+// UNet forward on instance k: z fp32 NCHW -> eps2 fp32 NHWC [2B*HW, ld] inside the slab
+void unet_fwd(dd_engine* E, int k, const float* z, int step_index, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  Run r{E, s, c.max_batch};
+  Ctx ctx = r.ctx(E->unet, E->inst[k].unet);
+  ctx.step_index = step_index;
+  const Tn& in = E->unet.t[E->unet_in];
+  HIPCHK(launch_nchw_f32_to_nhwc_bf16(z, act_ptr(ctx, in), c.max_batch, c.unet_in_channels, c.latent_size, c.latent_size, in.ld, in.ld, 1,
+                                      1.f, s));
+  run_fwd(E->unet, ctx);
+}
+
+void vae_fwd(dd_engine* E, int k, const float* x0, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  Run r{E, s, c.max_batch};
+  Ctx ctx = r.ctx(E->vae, E->inst[k].vae);
+  const Tn& in = E->vae.t[E->vae_in];
+  HIPCHK(launch_nchw_f32_to_nhwc_bf16(x0, act_ptr(ctx, in), c.max_batch, c.vae_latent_channels, c.latent_size, c.latent_size, in.ld,
+                                      in.ld, 0, 1.f / c.vae_scaling_factor, s));
+  run_fwd(E->vae, ctx);
+}
+
+// guide forward from the decoded image of instance k (bicubic -> resnet -> GAP) -> feat [B, D]
+void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  Run r{E, s, c.max_batch};
+  Ctx gc = r.ctx(E->guide, E->inst[k].guide);
+  Ctx vc = r.ctx(E->vae, E->inst[k].vae);
+  const Tn& img = E->vae.t[E->vae_out];
+  const Tn& gin = E->guide.t[E->guide_in];
+  HIPCHK(launch_bicubic(act_ptr(vc, img), img.ld, act_ptr(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
+  run_fwd(E->guide, gc);
+  const Tn& f = E->guide.t[E->guide_feat];
+  HIPCHK(launch_gap(act_ptr(gc, f), f.ld, E->inst[k].feat, c.max_batch, f.H * f.W, f.C, s));
+}
+
+// reverse of guide_fwd_from_image + vae_fwd: gfeat -> g_x0 (fp32 NCHW)
+void guide_vae_bwd(dd_engine* E, int k, float* g_x0, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  Run r{E, s, c.max_batch};
+  Ctx gc = r.ctx(E->guide, E->inst[k].guide);
+  Ctx vc = r.ctx(E->vae, E->inst[k].vae);
+  const Tn& f = E->guide.t[E->guide_feat];
+  // GAP^T; the ReLU mask of the last bottleneck is applied by that conv op's backward
+  HIPCHK(launch_gap_bwd(E->inst[k].gfeat, grad_ptr(gc, f), f.ld, c.max_batch, f.H * f.W, f.C, nullptr, 0, s));
+  run_bwd(E->guide, gc);
+  const Tn& gin = E->guide.t[E->guide_in];
+  const Tn& img = E->vae.t[E->vae_out];
+  // the guide and VAE gradient regions are disjoint parts of the shared gradient slab (see finalize)
+  HIPCHK(launch_bicubic_bwd(grad_ptr(gc, gin), gin.ld, grad_ptr(vc, img), img.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, s));
+  run_bwd(E->vae, vc);
+  const Tn& vin = E->vae.t[E->vae_in];
+  HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(vc, vin), 0, g_x0, c.max_batch, c.vae_latent_channels, c.latent_size, c.latent_size, vin.ld,
+                                 1.f / c.vae_scaling_factor, 0.f, 0, 0.f, 0.f, s));
+}
+
+// one guided forward step on instance k: z_in -> (z_next, x0, feat) ; energy accumulates into score, writes gfeat
+void guided_forward(dd_engine* E, int k, const float* z_in, int step_index, const int* targets, int normalize, float weight,
+                    float* score, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  auto& I = E->inst[k];
+  const int HW = c.latent_size * c.latent_size;
+  unet_fwd(E, k, z_in, step_index, s);
+  const Tn& out = E->unet.t[E->unet_out];
+  HIPCHK(launch_cfg_ddim((const float*)(I.unet + out.off), out.ld, z_in, I.z_next, I.x0, c.max_batch, c.unet_out_channels, HW,
+                         E->coef_table + (size_t)step_index * 8, s));
+  vae_fwd(E, k, I.x0, s);
+  guide_fwd_from_image(E, k, s);
+  HIPCHK(launch_energy(I.feat, E->Pc, E->Pg, targets, c.max_batch, E->pD, E->pK, E->sp.gs, E->sp.ls, E->sp.use_global, E->sp.use_local,
+                       normalize, weight, score, I.gfeat, s));
+}
+
+// reverse of guided_forward: given g_znext (may be null) returns g_z (fp32 NCHW) in g_z_out
+void guided_backward(dd_engine* E, int k, int step_index, const float* g_znext, float* g_z_out, float* g_x0_tmp, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  const int HW = c.latent_size * c.latent_size;
+  Run r{E, s, c.max_batch};
+  guide_vae_bwd(E, k, g_x0_tmp, s);
+  Ctx uc = r.ctx(E->unet, E->inst[k].unet);
+  uc.step_index = step_index;
+  const Tn& out = E->unet.t[E->unet_out];
+  HIPCHK(launch_cfg_ddim_bwd(g_x0_tmp, g_znext, grad_ptr(uc, out), out.ld, g_z_out, c.max_batch, c.unet_out_channels, HW,
+                             E->coef_table + (size_t)step_index * 8, s));
+  run_bwd(E->unet, uc);
+  const Tn& in = E->unet.t[E->unet_in];
+  HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, c.max_batch, c.unet_in_channels, HW, 1, s));
+}
+
+void set_config_defaults(dd_config& c) {
+  if (c.max_guidance_period < 1) c.max_guidance_period = 1;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+#define DD_TRY(E, ...)                                    \
+  try { __VA_ARGS__; return DD_OK; }                      \
+  catch (const std::exception& ex) { (E)->err = ex.what(); return DD_ERR_HIP; }
+
+extern "C" {
+
+int dd_create(const dd_config* cfg, dd_engine** out) {
+  if (!cfg || !out) return DD_ERR_ARG;
+  if (cfg->unet_levels > DD_MAX_LEVELS || cfg->vae_levels > DD_MAX_LEVELS || cfg->guide_stages > DD_MAX_LEVELS || cfg->max_batch < 1)
+    return DD_ERR_ARG;
+  dd_engine* e = new dd_engine();
+  e->cfg = *cfg;
+  set_config_defaults(e->cfg);
+  *out = e;
+  return DD_OK;
+}
+
+void dd_destroy(dd_engine* e) {
+  if (!e) return;
+  for (void* p : e->dev_allocs) hipFree(p);
+  delete e;
+}
+
+const char* dd_last_error(dd_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int dd_load_tensor(dd_engine* e, const char* model, const char* key, const float* data, int ndim, const int64_t* shape) {
+  if (!e || !model || !key || !data || ndim < 1 || ndim > 4) return DD_ERR_ARG;
+  if (e->finalized) { e->err = "dd_load_tensor after dd_finalize_weights"; return DD_ERR_STATE; }
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  e->raw[std::string(model) + "/" + key] = std::move(t);
+  return DD_OK;
+}
+
+int dd_finalize_weights(dd_engine* E) {
+  if (!E) return DD_ERR_ARG;
+  if (E->finalized) { E->err = "already finalized"; return DD_ERR_STATE; }
+  DD_TRY(E, {
+    const dd_config& c = E->cfg;
+    build_unet(E);
+    build_vae(E);
+    build_guide(E);
+    // time embedding MLP weights (fp32, setup-time only)
+    auto up = [&](const char* key) {
+      const HostTensor& t = E->get("unet", key);
+      float* d = (float*)E->dmalloc(t.data.size() * 4, false);
+      HIPCHK(hipMemcpy(d, t.data.data(), t.data.size() * 4, hipMemcpyHostToDevice));
+      return d;
+    };
+    E->temb_w1 = up("time_embedding.linear_1.weight"); E->temb_b1 = up("time_embedding.linear_1.bias");
+    E->temb_w2 = up("time_embedding.linear_2.weight"); E->temb_b2 = up("time_embedding.linear_2.bias");
+    E->raw.clear();
+    // activation slabs
+    const int P = c.enable_grad ? c.max_guidance_period : 1;
+    const int B = c.max_batch, L = c.latent_size;
+    const size_t zbytes = (size_t)B * std::max(c.unet_in_channels, c.vae_latent_channels) * L * L * 4;
+    E->inst.resize(P);
+    for (int k = 0; k < P; ++k) {
+      auto& I = E->inst[k];
+      I.unet = (char*)E->dmalloc(E->unet.act_bytes);
+      if (k == 0 || c.enable_grad) {
+        I.vae = (char*)E->dmalloc(E->vae.act_bytes);
+        I.guide = (char*)E->dmalloc(E->guide.act_bytes);
+      }
+      I.z_in = (float*)E->dmalloc(zbytes); I.z_next = (float*)E->dmalloc(zbytes); I.x0 = (float*)E->dmalloc(zbytes);
+      I.feat = (float*)E->dmalloc((size_t)B * c.guide_planes[c.guide_stages - 1] * c.guide_expansion * 4);
+      I.gfeat = (float*)E->dmalloc((size_t)B * c.guide_planes[c.guide_stages - 1] * c.guide_expansion * 4);
+    }
+    if (c.enable_grad) {
+      // UNet gradients alone; VAE and guide gradients live side by side (bicubic^T bridges them)
+      const size_t g = std::max(E->unet.grad_bytes, E->vae.grad_bytes + E->guide.grad_bytes);
+      E->grad_slab = (char*)E->dmalloc(g);
+      for (auto& t : E->guide.t) t.goff += E->vae.grad_bytes;
+    }
+    E->partial_cap = std::max({E->unet.scratch_partial, E->vae.scratch_partial, E->guide.scratch_partial, (size_t)1 << 20});
+    E->scratch_partial = (char*)E->dmalloc(E->partial_cap, false);
+    E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, (size_t)256});
+    E->scratch_tmp = (char*)E->dmalloc(E->tmp_cap);
+    const int maxG = std::max(c.unet_groups, c.vae_groups);
+    E->gn_scratch = (float*)E->dmalloc(groupnorm_scratch_bytes(2 * B, maxG), false);
+    for (auto& f : E->f32_tmp) f = (float*)E->dmalloc(zbytes);
+    E->img_tmp = (float*)E->dmalloc((size_t)B * 3 * 64 * L * L * 4);
+    E->score_tmp = (float*)E->dmalloc(256);
+    // cross-attention K/V buffers
+    E->ctx_bf16 = (bf16_t*)E->dmalloc((size_t)2 * B * c.text_len * rup(c.unet_cross_dim, 8) * 2);
+    for (auto& sl : E->cross_slots) {
+      bf16_t* k = (bf16_t*)E->dmalloc((size_t)2 * B * c.text_len * sl.C * 2);
+      bf16_t* v = (bf16_t*)E->dmalloc((size_t)2 * B * c.text_len * sl.C * 2);
+      E->cross_kv.push_back({k, v});
+    }
+    HIPCHK(hipDeviceSynchronize());
+    E->finalized = true;
+  });
+}
+
+int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alphas_cumprod, int num_train, float final_alpha,
+                    const dd_sampler_params* sp) {
+  if (!E || !timesteps || n < 1 || !alphas_cumprod || !sp) return DD_ERR_ARG;
+  if (!E->finalized) { E->err = "finalize first"; return DD_ERR_STATE; }
+  DD_TRY(E, {
+    const dd_config& c = E->cfg;
+    E->timesteps.assign(timesteps, timesteps + n);
+    E->sp = *sp;
+    std::vector<float> coef((size_t)n * 8, 0.f);
+    const int ratio = num_train / n;
+    for (int i = 0; i < n; ++i) {
+      const int t = timesteps[i], prev = t - ratio;
+      if (t < 0 || t >= num_train) throw std::runtime_error("timestep out of range");
+      const double a = alphas_cumprod[t], ap = prev >= 0 ? alphas_cumprod[prev] : final_alpha;
+      float* q = &coef[(size_t)i * 8];
+      q[0] = sp->guidance_scale; q[1] = (float)sqrt(a); q[2] = (float)sqrt(1 - a); q[3] = (float)sqrt(ap); q[4] = (float)sqrt(1 - ap);
+    }
+    E->coef_table = (float*)E->dmalloc(coef.size() * 4, false);
+    HIPCHK(hipMemcpy(E->coef_table, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+    // sinusoidal timestep embedding (diffusers Timesteps: flip_sin_to_cos, freq_shift) on host, MLP + projections on GPU (fp32)
+    const int C0 = c.unet_block_out_channels[0], half = C0 / 2, TE = C0 * 4;
+    std::vector<float> sinus((size_t)n * C0);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < half; ++j) {
+        const float freq = expf(-logf(10000.f) * (float)j / ((float)half - c.unet_freq_shift));
+        const float a = (float)timesteps[i] * freq;
+        const float sn = sinf(a), cs = cosf(a);
+        if (c.unet_flip_sin_to_cos) { sinus[(size_t)i * C0 + j] = cs; sinus[(size_t)i * C0 + half + j] = sn; }
+        else { sinus[(size_t)i * C0 + j] = sn; sinus[(size_t)i * C0 + half + j] = cs; }
+      }
+    float* d_sin = (float*)E->dmalloc(sinus.size() * 4, false);
+    HIPCHK(hipMemcpy(d_sin, sinus.data(), sinus.size() * 4, hipMemcpyHostToDevice));
+    float* d_h1 = (float*)E->dmalloc((size_t)n * TE * 4, false);
+    float* d_emb = (float*)E->dmalloc((size_t)n * TE * 4, false);
+    HIPCHK(launch_linear_f32(d_sin, E->temb_w1, E->temb_b1, d_h1, n, TE, C0, 0, nullptr));
+    HIPCHK(launch_linear_f32(d_h1, E->temb_w2, E->temb_b2, d_emb, n, TE, TE, 1, nullptr));
+    for (ConvW* cw : E->temb_convs) {
+      cw->bias_table = (float*)E->dmalloc((size_t)n * cw->Cout * 4, false);
+      HIPCHK(launch_linear_f32(d_emb, cw->temb_w, cw->temb_b, cw->bias_table, n, cw->Cout, TE, 1, nullptr));
+      // + conv1.bias
+      HIPCHK(hipDeviceSynchronize());
+      std::vector<float> tab((size_t)n * cw->Cout);
+      HIPCHK(hipMemcpy(tab.data(), cw->bias_table, tab.size() * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; ++i)
+        for (int o = 0; o < cw->Cout; ++o) tab[(size_t)i * cw->Cout + o] += cw->conv_bias_host.empty() ? 0.f : cw->conv_bias_host[o];
+      HIPCHK(hipMemcpy(cw->bias_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipDeviceSynchronize());
+  });
+}
+
+int dd_set_prototypes(dd_engine* E, const float* Pc, const float* Pg, int C, int K, int D) {
+  if (!E || C < 1 || D < 1) return DD_ERR_ARG;
+  DD_TRY(E, {
+    E->pC = C; E->pK = K; E->pD = D;
+    E->Pc = nullptr; E->Pg = nullptr;
+    if (Pc) { E->Pc = (float*)E->dmalloc((size_t)C * D * 4, false); HIPCHK(hipMemcpy(E->Pc, Pc, (size_t)C * D * 4, hipMemcpyHostToDevice)); }
+    if (Pg) { E->Pg = (float*)E->dmalloc((size_t)C * K * D * 4, false); HIPCHK(hipMemcpy(E->Pg, Pg, (size_t)C * K * D * 4, hipMemcpyHostToDevice)); }
+  });
+}
+
+int dd_set_prompt(dd_engine* E, const float* embeds, int B, void* stream) {
+  if (!E || !embeds) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = 2 * B * c.text_len, ld = rup(c.unet_cross_dim, 8);
+    // [rows, cross_dim] fp32 -> bf16 rows (treated as NCHW with H*W = 1 per row)
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(embeds, E->ctx_bf16, rows, c.unet_cross_dim, 1, 1, ld, ld, 0, 1.f, s));
+    for (size_t i = 0; i < E->cross_slots.size(); ++i) {
+      auto& sl = E->cross_slots[i];
+      for (int which = 0; which < 2; ++which) {
+        ConvW* w = which ? sl.wv : sl.wk;
+        ConvGemmParams p; memset(&p, 0, sizeof p);
+        p.alpha = 1.f; p.partial = (float*)E->scratch_partial;
+        p.x = E->ctx_bf16; p.x_ld = ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
+        p.y = which ? E->cross_kv[i].second : E->cross_kv[i].first; p.y_ld = sl.C;
+        p.B = 1; p.H = rows; p.W = 1; p.Ho = rows; p.Wo = 1; p.stride = 1;
+        p.cin = w->sf.cin; p.ntaps = w->sf.ntaps; p.M = rows; p.N = w->sf.N; p.K = w->sf.K;
+        HIPCHK(launch_conv_gemm(p, E->partial_cap, s));
+      }
+    }
+  });
+}
+
+int dd_add_noise(dd_engine* E, const float* x, const float* noise, float* out, int B, int step_index, void* stream) {
+  if (!E || !x || !noise || !out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    if (step_index < 0 || step_index >= (int)E->timesteps.size()) throw std::runtime_error("step_index out of range");
+    const dd_config& c = E->cfg;
+    // coef_table[step][1..2] = sqrt(a_t), sqrt(1-a_t)
+    HIPCHK(launch_axpby(x, noise, out, (size_t)B * c.unet_in_channels * c.latent_size * c.latent_size,
+                        E->coef_table + (size_t)step_index * 8 + 1, (hipStream_t)stream));
+  });
+}
+
+int dd_unet_forward(dd_engine* E, const float* z, int step_index, float* eps2_out, int B, void* stream) {
+  if (!E || !z || !eps2_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    unet_fwd(E, 0, z, step_index, s);
+    const Tn& out = E->unet.t[E->unet_out];
+    HIPCHK(launch_nhwc_to_nchw_f32(E->inst[0].unet + out.off, 1, eps2_out, 2 * B, c.unet_out_channels, c.latent_size, c.latent_size, out.ld,
+                                   1.f, 0.f, 0, 0.f, 0.f, s));
+  });
+}
+
+int dd_denoise_step(dd_engine* E, const float* z, int step_index, float* z_prev_out, float* x0_out, int B, void* stream) {
+  if (!E || !z || !z_prev_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    if (step_index < 0 || step_index >= (int)E->timesteps.size()) throw std::runtime_error("step_index out of range");
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    unet_fwd(E, 0, z, step_index, s);
+    const Tn& out = E->unet.t[E->unet_out];
+    HIPCHK(launch_cfg_ddim((const float*)(E->inst[0].unet + out.off), out.ld, z, z_prev_out, x0_out, B, c.unet_out_channels,
+                           c.latent_size * c.latent_size, E->coef_table + (size_t)step_index * 8, s));
+  });
+}
+
+int dd_decode(dd_engine* E, const float* z, float* image_out, int denormalize, int B, void* stream) {
+  if (!E || !z || !image_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    vae_fwd(E, 0, z, s);
+    const Tn& img = E->vae.t[E->vae_out];
+    HIPCHK(launch_nhwc_to_nchw_f32(E->inst[0].vae + img.off, 0, image_out, B, c.vae_out_channels, img.H, img.W, img.ld,
+                                   denormalize ? 0.5f : 1.f, denormalize ? 0.5f : 0.f, denormalize, 0.f, 1.f, s));
+  });
+}
+
+int dd_guide_encode(dd_engine* E, const float* images, float* feats, int B, void* stream) {
+  if (!E || !images || !feats) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    Run r{E, s, B};
+    Ctx gc = r.ctx(E->guide, E->inst[0].guide);
+    const Tn& gin = E->guide.t[E->guide_in];
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(images, act_ptr(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, 0, 1.f, s));
+    run_fwd(E->guide, gc);
+    const Tn& f = E->guide.t[E->guide_feat];
+    HIPCHK(launch_gap(act_ptr(gc, f), f.ld, feats, B, f.H * f.W, f.C, s));
+  });
+}
+
+int dd_transform_guidance(dd_engine* E, const float* z, const int* targets, const float* ch_e, const float* ch_b, int first_step_index,
+                          int P, float* z_out, float* score_out, float* grad_eb_out, int B, void* stream) {
+  if (!E || !z || !targets || !ch_e || !ch_b || !z_out || P < 1) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (!c.enable_grad) throw std::runtime_error("engine created with enable_grad=0");
+    if (P > (int)E->inst.size()) throw std::runtime_error("guidance period exceeds max_guidance_period");
+    if (first_step_index < 0 || first_step_index + P > (int)E->timesteps.size()) throw std::runtime_error("guide steps out of range");
+    if ((E->sp.use_global && !E->Pc) || (E->sp.use_local && !E->Pg)) throw std::runtime_error("prototypes not set");
+    hipStream_t s = (hipStream_t)stream;
+    const int BC = B * c.unet_in_channels, HW = c.latent_size * c.latent_size;
+    float* score = score_out ? score_out : E->score_tmp;
+    HIPCHK(hipMemsetAsync(score, 0, sizeof(float), s));
+    // z0 = z*(1+e)+b  (generate_data.py:696)
+    HIPCHK(launch_affine(z, ch_e, ch_b, E->inst[0].z_in, BC, HW, s));
+    const float weight = 1.f / (float)E->sp.guidance_period;   // score / args.guidance_period (:719)
+    for (int k = 0; k < P; ++k) {
+      const float* zin = E->inst[k].z_in;
+      guided_forward(E, k, zin, first_step_index + k, targets, 0, weight, score, s);
+      if (k + 1 < P) HIPCHK(hipMemcpyAsync(E->inst[k + 1].z_in, E->inst[k].z_next, (size_t)BC * HW * 4, hipMemcpyDeviceToDevice, s));
+    }
+    float* g_next = nullptr;
+    float* gbuf[2] = {E->f32_tmp[0], E->f32_tmp[1]};
+    for (int k = P - 1; k >= 0; --k) {
+      float* g_z = gbuf[k & 1];
+      guided_backward(E, k, first_step_index + k, g_next, g_z, E->f32_tmp[2], s);
+      g_next = g_z;
+    }
+    if (grad_eb_out) HIPCHK(hipMemcpyAsync(grad_eb_out, g_next, (size_t)BC * HW * 4, hipMemcpyDeviceToDevice, s));
+    // e -= rho*ge ; b -= rho*gb ; z' = clamp(z*(1+e)+b, z-c, z+c)  (:721-728)
+    HIPCHK(launch_transform_update(z, g_next, ch_e, ch_b, z_out, BC, HW, E->sp.rho, E->sp.constraint_value, s));
+  });
+}
+
+int dd_direct_guidance(dd_engine* E, const float* z, const int* targets, int step_index, float* z_next_out, float* x0_out,
+                       float* score_out, float* grad_z_out, int B, void* stream) {
+  if (!E || !z || !targets || !z_next_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (!c.enable_grad) throw std::runtime_error("engine created with enable_grad=0");
+    if (step_index < 0 || step_index >= (int)E->timesteps.size()) throw std::runtime_error("step_index out of range");
+    if ((E->sp.use_global && !E->Pc) || (E->sp.use_local && !E->Pg)) throw std::runtime_error("prototypes not set");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * c.unet_in_channels * c.latent_size * c.latent_size;
+    float* score = score_out ? score_out : E->score_tmp;
+    HIPCHK(hipMemsetAsync(score, 0, sizeof(float), s));
+    HIPCHK(hipMemcpyAsync(E->inst[0].z_in, z, n * 4, hipMemcpyDeviceToDevice, s));
+    guided_forward(E, 0, E->inst[0].z_in, step_index, targets, 1, 1.f, score, s);
+    float* g_z = E->f32_tmp[0];
+    guided_backward(E, 0, step_index, nullptr, g_z, E->f32_tmp[2], s);
+    if (grad_z_out) HIPCHK(hipMemcpyAsync(grad_z_out, g_z, n * 4, hipMemcpyDeviceToDevice, s));
+    if (x0_out) HIPCHK(hipMemcpyAsync(x0_out, E->inst[0].x0, n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(launch_sub_scaled(E->inst[0].z_next, g_z, z_next_out, n, E->sp.rho, s));   // :762
+  });
+}
+
+int dd_expand(dd_engine* E, const dd_expand_args* a, void* stream) {
+  if (!E || !a || !a->image_latents || !a->noise || !a->z_out) return DD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)E->timesteps.size();
+  if (a->start_index < 0 || a->start_index >= n) { E->err = "start_index out of range"; return DD_ERR_ARG; }
+  int rc = dd_add_noise(E, a->image_latents, a->noise, E->f32_tmp[3], a->B, a->start_index, stream);
+  if (rc) return rc;
+  float* cur = E->f32_tmp[3];
+  float* nxt = E->f32_tmp[4];
+  for (int i = a->start_index; i < n; ++i) {
+    if (a->guidance_type == 1 && a->guide_count > 0 && i == a->guide_first) {
+      // transform guidance at t == guide_timesteps[0], then the step is executed again from the corrected latent (:1203-1207)
+      rc = dd_transform_guidance(E, cur, a->targets, a->e, a->b, a->guide_first, a->guide_count, nxt, a->score_out, nullptr, a->B, stream);
+      if (rc) return rc;
+      std::swap(cur, nxt);
+      rc = dd_denoise_step(E, cur, i, nxt, nullptr, a->B, stream);
+    } else if (a->guidance_type == 2 && i >= a->guide_first && i < a->guide_first + a->guide_count) {
+      rc = dd_direct_guidance(E, cur, a->targets, i, nxt, nullptr, a->score_out, nullptr, a->B, stream);
+    } else {
+      rc = dd_denoise_step(E, cur, i, nxt, nullptr, a->B, stream);
+    }
+    if (rc) return rc;
+    std::swap(cur, nxt);
+  }
+  try {
+    const dd_config& c = E->cfg;
+    HIPCHK(hipMemcpyAsync(a->z_out, cur, (size_t)a->B * c.unet_in_channels * c.latent_size * c.latent_size * 4, hipMemcpyDeviceToDevice, s));
+  } catch (const std::exception& ex) { E->err = ex.what(); return DD_ERR_HIP; }
+  if (a->image_out) return dd_decode(E, cur, a->image_out, 1, a->B, stream);
+  return DD_OK;
+}
+
+// ---- per-module VJP diagnostics (parity tests of the hand-derived reverse programs against torch.autograd) ----
+int dd_unet_vjp(dd_engine* E, const float* z, int step_index, const float* g_eps2, float* g_z_out, int B, void* stream) {
+  if (!E || !z || !g_eps2 || !g_z_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (!c.enable_grad) throw std::runtime_error("engine created with enable_grad=0");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = c.latent_size * c.latent_size;
+    unet_fwd(E, 0, z, step_index, s);
+    Run r{E, s, B};
+    Ctx uc = r.ctx(E->unet, E->inst[0].unet);
+    uc.step_index = step_index;
+    const Tn& out = E->unet.t[E->unet_out];
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(g_eps2, grad_ptr(uc, out), 2 * B, c.unet_out_channels, c.latent_size, c.latent_size, out.ld, out.ld, 0,
+                                        1.f, s));
+    run_bwd(E->unet, uc);
+    const Tn& in = E->unet.t[E->unet_in];
+    HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, B, c.unet_in_channels, HW, 0, s));
+  });
+}
+
+int dd_decode_vjp(dd_engine* E, const float* z, const float* g_image, float* g_z_out, int B, void* stream) {
+  if (!E || !z || !g_image || !g_z_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (!c.enable_grad) throw std::runtime_error("engine created with enable_grad=0");
+    hipStream_t s = (hipStream_t)stream;
+    vae_fwd(E, 0, z, s);
+    Run r{E, s, B};
+    Ctx vc = r.ctx(E->vae, E->inst[0].vae);
+    const Tn& img = E->vae.t[E->vae_out];
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(g_image, grad_ptr(vc, img), B, c.vae_out_channels, img.H, img.W, img.ld, img.ld, 0, 1.f, s));
+    run_bwd(E->vae, vc);
+    const Tn& vin = E->vae.t[E->vae_in];
+    HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(vc, vin), 0, g_z_out, B, c.vae_latent_channels, c.latent_size, c.latent_size, vin.ld,
+                                   1.f / c.vae_scaling_factor, 0.f, 0, 0.f, 0.f, s));
+  });
+}
+
+int dd_guide_vjp(dd_engine* E, const float* images, const float* g_feats, float* g_images_out, int B, void* stream) {
+  if (!E || !images || !g_feats || !g_images_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (!c.enable_grad) throw std::runtime_error("engine created with enable_grad=0");
+    hipStream_t s = (hipStream_t)stream;
+    Run r{E, s, B};
+    Ctx gc = r.ctx(E->guide, E->inst[0].guide);
+    const Tn& gin = E->guide.t[E->guide_in];
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(images, act_ptr(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, 0, 1.f, s));
+    run_fwd(E->guide, gc);
+    const Tn& f = E->guide.t[E->guide_feat];
+    HIPCHK(launch_gap_bwd(g_feats, grad_ptr(gc, f), f.ld, B, f.H * f.W, f.C, nullptr, 0, s));
+    run_bwd(E->guide, gc);
+    HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(gc, gin), 0, g_images_out, B, 3, gin.H, gin.W, gin.ld, 1.f, 0.f, 0, 0.f, 0.f, s));
+  });
+}
+
+size_t dd_workspace_bytes(dd_engine* e) { return e ? e->total_bytes : 0; }
+double dd_flops_last(dd_engine* e) { if (!e) return 0; const double f = e->flops; e->flops = 0; return f; }
+
+}  // extern "C"

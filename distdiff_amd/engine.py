@@ -1,0 +1,276 @@
+"""Python host side of the expansion engine: a thin ctypes layer over include/distdiff_hip.h.
+
+PyTorch supplies device memory and the HIP stream; all arithmetic happens in libdistdiff_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EngineConfig
+
+DD_MAX_LEVELS = 8
+vp = C.c_void_p
+_IA = C.c_int * DD_MAX_LEVELS
+
+
+class DDConfig(C.Structure):
+    _fields_ = [
+        ("unet_in_channels", C.c_int), ("unet_out_channels", C.c_int), ("unet_levels", C.c_int),
+        ("unet_block_out_channels", _IA), ("unet_layers_per_block", C.c_int),
+        ("unet_down_attn", _IA), ("unet_up_attn", _IA),
+        ("unet_num_heads", C.c_int), ("unet_cross_dim", C.c_int), ("unet_groups", C.c_int),
+        ("unet_eps", C.c_float), ("unet_freq_shift", C.c_float), ("unet_flip_sin_to_cos", C.c_int),
+        ("vae_latent_channels", C.c_int), ("vae_out_channels", C.c_int), ("vae_levels", C.c_int),
+        ("vae_block_out_channels", _IA), ("vae_layers_per_block", C.c_int), ("vae_groups", C.c_int),
+        ("vae_eps", C.c_float), ("vae_scaling_factor", C.c_float),
+        ("guide_stem", C.c_int), ("guide_stages", C.c_int), ("guide_planes", _IA), ("guide_blocks", _IA),
+        ("guide_expansion", C.c_int), ("guide_input_size", C.c_int), ("guide_bn_eps", C.c_float),
+        ("latent_size", C.c_int), ("text_len", C.c_int), ("max_batch", C.c_int),
+        ("enable_grad", C.c_int), ("max_guidance_period", C.c_int),
+    ]
+
+
+class DDSamplerParams(C.Structure):
+    _fields_ = [("guidance_scale", C.c_float), ("gs", C.c_float), ("ls", C.c_float), ("rho", C.c_float),
+                ("constraint_value", C.c_float), ("use_global", C.c_int), ("use_local", C.c_int),
+                ("guidance_period", C.c_int)]
+
+
+class DDExpandArgs(C.Structure):
+    _fields_ = [("image_latents", vp), ("noise", vp), ("e", vp), ("b", vp), ("targets", vp), ("B", C.c_int),
+                ("start_index", C.c_int), ("guidance_type", C.c_int), ("guide_first", C.c_int), ("guide_count", C.c_int),
+                ("z_out", vp), ("image_out", vp), ("score_out", vp)]
+
+
+def _declare(l):
+    i, f = C.c_int, C.c_float
+    l.dd_create.argtypes = [C.POINTER(DDConfig), C.POINTER(vp)]
+    l.dd_destroy.argtypes = [vp]
+    l.dd_destroy.restype = None
+    l.dd_last_error.argtypes = [vp]
+    l.dd_last_error.restype = C.c_char_p
+    l.dd_load_tensor.argtypes = [vp, C.c_char_p, C.c_char_p, vp, i, C.POINTER(C.c_int64)]
+    l.dd_finalize_weights.argtypes = [vp]
+    l.dd_set_schedule.argtypes = [vp, vp, i, vp, i, f, C.POINTER(DDSamplerParams)]
+    l.dd_set_prototypes.argtypes = [vp, vp, vp, i, i, i]
+    l.dd_set_prompt.argtypes = [vp, vp, i, vp]
+    l.dd_add_noise.argtypes = [vp, vp, vp, vp, i, i, vp]
+    l.dd_denoise_step.argtypes = [vp, vp, i, vp, vp, i, vp]
+    l.dd_transform_guidance.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, vp]
+    l.dd_direct_guidance.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, i, vp]
+    l.dd_decode.argtypes = [vp, vp, vp, i, i, vp]
+    l.dd_expand.argtypes = [vp, C.POINTER(DDExpandArgs), vp]
+    l.dd_guide_encode.argtypes = [vp, vp, vp, i, vp]
+    l.dd_unet_forward.argtypes = [vp, vp, i, vp, i, vp]
+    l.dd_unet_vjp.argtypes = [vp, vp, i, vp, vp, i, vp]
+    l.dd_decode_vjp.argtypes = [vp, vp, vp, vp, i, vp]
+    l.dd_guide_vjp.argtypes = [vp, vp, vp, vp, i, vp]
+    l.dd_workspace_bytes.argtypes = [vp]
+    l.dd_workspace_bytes.restype = C.c_size_t
+    l.dd_flops_last.argtypes = [vp]
+    l.dd_flops_last.restype = C.c_double
+
+
+def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
+    c = DDConfig()
+    u, v, g = cfg.unet, cfg.vae, cfg.guide
+
+    def arr(xs):
+        a = _IA()
+        for k, x in enumerate(xs):
+            a[k] = int(x)
+        return a
+
+    c.unet_in_channels, c.unet_out_channels, c.unet_levels = u.in_channels, u.out_channels, len(u.block_out_channels)
+    c.unet_block_out_channels = arr(u.block_out_channels)
+    c.unet_layers_per_block = u.layers_per_block
+    c.unet_down_attn, c.unet_up_attn = arr(u.down_attn), arr(u.up_attn)
+    c.unet_num_heads, c.unet_cross_dim, c.unet_groups = u.num_heads, u.cross_attention_dim, u.norm_num_groups
+    c.unet_eps, c.unet_freq_shift, c.unet_flip_sin_to_cos = u.norm_eps, u.freq_shift, int(u.flip_sin_to_cos)
+    c.vae_latent_channels, c.vae_out_channels, c.vae_levels = v.latent_channels, v.out_channels, len(v.block_out_channels)
+    c.vae_block_out_channels = arr(v.block_out_channels)
+    c.vae_layers_per_block, c.vae_groups, c.vae_eps, c.vae_scaling_factor = v.layers_per_block, v.norm_num_groups, v.norm_eps, v.scaling_factor
+    c.guide_stem, c.guide_stages = g.stem_channels, len(g.planes)
+    c.guide_planes, c.guide_blocks = arr(g.planes), arr(g.blocks)
+    c.guide_expansion, c.guide_input_size, c.guide_bn_eps = g.expansion, g.input_size, g.bn_eps
+    c.latent_size, c.text_len, c.max_batch = cfg.latent_size, cfg.text_len, cfg.max_batch
+    c.enable_grad, c.max_guidance_period = int(enable_grad), int(max_guidance_period)
+    return c
+
+
+def _p(t):
+    return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+def _stream():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine per device. Mirrors the objects the reference builds at generate_data.py:863-922, 1100-1125."""
+
+    def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.L = _lib.lib()
+        self._h = vp()
+        cc = _to_c_config(cfg, enable_grad, max_guidance_period)
+        self._chk(self.L.dd_create(C.byref(cc), C.byref(self._h)), "dd_create")
+        for model in ("unet", "vae", "guide"):
+            for key, t in weights[model].items():
+                if key.startswith("fc.") or key.endswith("num_batches_tracked"):
+                    continue
+                a = t.detach().float().contiguous().cpu()
+                shape = (C.c_int64 * a.dim())(*a.shape)
+                self._chk(self.L.dd_load_tensor(self._h, model.encode(), key.encode(), vp(a.data_ptr()), a.dim(), shape),
+                          "dd_load_tensor " + key)
+        self._chk(self.L.dd_finalize_weights(self._h), "dd_finalize_weights")
+        self.n_steps = 0
+        self.B = cfg.max_batch
+        self._keep = []
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.L.dd_last_error(self._h).decode() if self._h else ""
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+
+    def close(self):
+        if self._h:
+            torch.cuda.synchronize()
+            self.L.dd_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------------------------
+    def set_schedule(self, timesteps, alphas_cumprod, final_alpha_cumprod, guidance_scale=7.5, gs=1.0, ls=1.0, rho=10.0,
+                     constraint_value=0.2, use_global=True, use_local=True, guidance_period=2):
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))
+        ac = np.ascontiguousarray(np.asarray(alphas_cumprod, dtype=np.float32))
+        sp = DDSamplerParams(guidance_scale, gs, ls, rho, constraint_value, int(use_global), int(use_local), int(guidance_period))
+        self._chk(self.L.dd_set_schedule(self._h, ts.ctypes.data_as(vp), len(ts), ac.ctypes.data_as(vp), len(ac),
+                                         float(final_alpha_cumprod), C.byref(sp)), "dd_set_schedule")
+        self.n_steps = len(ts)
+        self.timesteps = [int(t) for t in ts]
+
+    def set_prototypes(self, Pc, Pg):
+        pc = Pc.detach().float().contiguous().cpu() if Pc is not None else None
+        pg = Pg.detach().float().contiguous().cpu() if Pg is not None else None
+        ref = pc if pc is not None else pg
+        Cn, D = ref.shape[0], ref.shape[-1]
+        K = pg.shape[1] if pg is not None else 1
+        self._chk(self.L.dd_set_prototypes(self._h, _p(pc), _p(pg), Cn, K, D), "dd_set_prototypes")
+
+    def set_prompt(self, embeds_2b):
+        """embeds_2b: device fp32 [2B, text_len, cross_dim], negative (uncond) half first (generate_data.py:1184)."""
+        e = embeds_2b.to(self.device, torch.float32).contiguous()
+        assert e.shape[0] == 2 * self.B
+        self._chk(self.L.dd_set_prompt(self._h, _p(e), self.B, _stream()), "dd_set_prompt")
+        self._keep = [e]
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def _f(self, t):
+        t = t.to(self.device, torch.float32).contiguous()
+        return t
+
+    def add_noise(self, x, noise, step_index):
+        x, noise = self._f(x), self._f(noise)
+        out = torch.empty_like(x)
+        self._chk(self.L.dd_add_noise(self._h, _p(x), _p(noise), _p(out), x.shape[0], step_index, _stream()), "dd_add_noise")
+        return out
+
+    def unet_forward(self, z, step_index):
+        z = self._f(z)
+        out = torch.empty((2 * z.shape[0],) + tuple(z.shape[1:]), device=self.device, dtype=torch.float32)
+        self._chk(self.L.dd_unet_forward(self._h, _p(z), step_index, _p(out), z.shape[0], _stream()), "dd_unet_forward")
+        return out
+
+    def denoise_step(self, z, step_index):
+        z = self._f(z)
+        zp, x0 = torch.empty_like(z), torch.empty_like(z)
+        self._chk(self.L.dd_denoise_step(self._h, _p(z), step_index, _p(zp), _p(x0), z.shape[0], _stream()), "dd_denoise_step")
+        return zp, x0
+
+    def transform_guidance(self, z, targets, e, b, first_step_index, P):
+        z, e, b = self._f(z), self._f(e).reshape(-1), self._f(b).reshape(-1)
+        tg = targets.to(self.device, torch.int32).contiguous()
+        out = torch.empty_like(z)
+        score = torch.zeros(1, device=self.device)
+        gz0 = torch.empty_like(z)
+        self._chk(self.L.dd_transform_guidance(self._h, _p(z), _p(tg), _p(e), _p(b), first_step_index, P, _p(out), _p(score),
+                                               _p(gz0), z.shape[0], _stream()), "dd_transform_guidance")
+        return out, score, gz0
+
+    def direct_guidance(self, z, targets, step_index):
+        z = self._f(z)
+        tg = targets.to(self.device, torch.int32).contiguous()
+        zn, x0, gz = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        score = torch.zeros(1, device=self.device)
+        self._chk(self.L.dd_direct_guidance(self._h, _p(z), _p(tg), step_index, _p(zn), _p(x0), _p(score), _p(gz), z.shape[0],
+                                            _stream()), "dd_direct_guidance")
+        return zn, x0, score, gz
+
+    def decode(self, z, denormalize=True):
+        z = self._f(z)
+        L8 = self.cfg.latent_size * 8
+        img = torch.empty((z.shape[0], self.cfg.vae.out_channels, L8, L8), device=self.device, dtype=torch.float32)
+        self._chk(self.L.dd_decode(self._h, _p(z), _p(img), int(denormalize), z.shape[0], _stream()), "dd_decode")
+        return img
+
+    def guide_encode(self, images):
+        x = self._f(images)
+        f = torch.empty((x.shape[0], self.cfg.guide.feature_dim), device=self.device, dtype=torch.float32)
+        self._chk(self.L.dd_guide_encode(self._h, _p(x), _p(f), x.shape[0], _stream()), "dd_guide_encode")
+        return f
+
+    def expand(self, image_latents, noise, e, b, targets, start_index, guidance_type, guide_first, guide_count, want_image=True):
+        """guidance_type: None | 'transform_guidance' | 'direct_guidance' (generate_data.py:1203-1218)."""
+        lat, nz = self._f(image_latents), self._f(noise)
+        B = lat.shape[0]
+        e = self._f(e).reshape(-1) if e is not None else torch.zeros(B * 4, device=self.device)
+        b = self._f(b).reshape(-1) if b is not None else torch.zeros(B * 4, device=self.device)
+        tg = targets.to(self.device, torch.int32).contiguous()
+        a = DDExpandArgs()
+        z_out = torch.empty_like(lat)
+        L8 = self.cfg.latent_size * 8
+        img = torch.empty((B, 3, L8, L8), device=self.device) if want_image else None
+        score = torch.zeros(1, device=self.device)
+        a.image_latents, a.noise, a.e, a.b, a.targets, a.B = _p(lat), _p(nz), _p(e), _p(b), _p(tg), B
+        a.start_index = start_index
+        a.guidance_type = {None: 0, "": 0, "transform_guidance": 1, "direct_guidance": 2}[guidance_type]
+        a.guide_first, a.guide_count = guide_first, guide_count
+        a.z_out, a.image_out, a.score_out = _p(z_out), _p(img), _p(score)
+        self._chk(self.L.dd_expand(self._h, C.byref(a), _stream()), "dd_expand")
+        return z_out, img, score
+
+    # ---- per-module VJP diagnostics -------------------------------------------------------------
+    def unet_vjp(self, z, step_index, g_eps2):
+        z, g = self._f(z), self._f(g_eps2)
+        out = torch.empty_like(z)
+        self._chk(self.L.dd_unet_vjp(self._h, _p(z), step_index, _p(g), _p(out), z.shape[0], _stream()), "dd_unet_vjp")
+        return out
+
+    def decode_vjp(self, z, g_image):
+        z, g = self._f(z), self._f(g_image)
+        out = torch.empty_like(z)
+        self._chk(self.L.dd_decode_vjp(self._h, _p(z), _p(g), _p(out), z.shape[0], _stream()), "dd_decode_vjp")
+        return out
+
+    def guide_vjp(self, images, g_feats):
+        x, g = self._f(images), self._f(g_feats)
+        out = torch.empty_like(x)
+        self._chk(self.L.dd_guide_vjp(self._h, _p(x), _p(g), _p(out), x.shape[0], _stream()), "dd_guide_vjp")
+        return out
+
+    def workspace_bytes(self):
+        return int(self.L.dd_workspace_bytes(self._h))
+
+    def flops_last(self):
+        return float(self.L.dd_flops_last(self._h))

@@ -1,0 +1,136 @@
+/* distdiff_hip.h — production C ABI of libdistdiff_hip.so: the MI355X-native replacement of the guided
+ * DDIM expansion hot path of haoweiz23/DistDiff (generate_data.py). No torch types cross this boundary:
+ * plain pointers, sizes, a HIP stream handle. Every call returns 0 or a negative dd_status and leaves a
+ * message in dd_last_error(); no C++ exception crosses the ABI.
+ *
+ * The reference has no FFI (pure Python over diffusers/timm); each entry point replaces the Python
+ * function / third-party call named beside it (file:line in /root/reference):
+ *
+ *   dd_create / dd_load_tensor / dd_finalize_weights
+ *        UNet2DConditionModel.from_pretrained, AutoencoderKL.from_pretrained  generate_data.py:912-922
+ *        create_model(...) + checkpoint load                                   model_utils.py:43-104
+ *   dd_set_schedule        DDIMScheduler.from_pretrained + retrieve_timesteps   generate_data.py:863, 1043-1044
+ *   dd_set_prototypes      total_global_proto / total_local_proto               generate_data.py:1113-1125
+ *   dd_set_prompt          prompt_embeds = cat[negative, prompt]                generate_data.py:1147-1148, 1184
+ *   dd_add_noise           noise_scheduler.add_noise                            generate_data.py:1176
+ *   dd_denoise_step        denoise_one_step                                     generate_data.py:109-121
+ *   dd_transform_guidance  transform_guidance (+ linfball_proj)                 generate_data.py:687-732, 124-137
+ *   dd_direct_guidance     direct_guidance                                      generate_data.py:735-767
+ *   dd_decode              vae.decode + image_processor.postprocess             generate_data.py:1221-1228
+ *   dd_expand              the per-(batch, expand index) denoise loop           generate_data.py:1161-1228
+ *   dd_guide_encode        image_encoder.encode_image                           model_utils.py:29-41
+ *
+ * Ownership: every tensor argument is caller-owned DEVICE memory unless marked host; the engine borrows it for
+ * the duration of the enqueued work. The engine owns packed weights and its activation workspace.
+ * Threading: one engine per device, not re-entrant. All work is enqueued on the caller's stream; nothing
+ * synchronises unless documented (dd_finalize_weights and dd_set_schedule do, they are one-time setup).
+ * Layouts: latents / images are NCHW fp32 exactly as the reference's torch tensors ([B,4,L,L], [B,3,8L,8L]);
+ * text embeddings [2B, text_len, cross_dim] fp32 with the negative (unconditional) half first.
+ */
+#ifndef DISTDIFF_HIP_H
+#define DISTDIFF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dd_engine dd_engine;
+
+enum dd_status { DD_OK = 0, DD_ERR_ARG = -1, DD_ERR_HIP = -2, DD_ERR_STATE = -3, DD_ERR_WEIGHT = -4, DD_ERR_OOM = -5 };
+
+#define DD_MAX_LEVELS 8
+
+typedef struct dd_config {
+  /* UNet2DConditionModel (unet/config.json) */
+  int unet_in_channels, unet_out_channels, unet_levels;
+  int unet_block_out_channels[DD_MAX_LEVELS];
+  int unet_layers_per_block;
+  int unet_down_attn[DD_MAX_LEVELS], unet_up_attn[DD_MAX_LEVELS];
+  int unet_num_heads, unet_cross_dim, unet_groups;
+  float unet_eps, unet_freq_shift;
+  int unet_flip_sin_to_cos;
+  /* AutoencoderKL decoder (vae/config.json) */
+  int vae_latent_channels, vae_out_channels, vae_levels;
+  int vae_block_out_channels[DD_MAX_LEVELS];
+  int vae_layers_per_block, vae_groups;
+  float vae_eps, vae_scaling_factor;
+  /* guide model: timm resnet50 family (model_utils.py:47-55) */
+  int guide_stem, guide_stages;
+  int guide_planes[DD_MAX_LEVELS], guide_blocks[DD_MAX_LEVELS];
+  int guide_expansion, guide_input_size;
+  float guide_bn_eps;
+  /* problem size */
+  int latent_size, text_len, max_batch;
+  int enable_grad;      /* 1: build the VJP programs and stash activations (energy guidance) */
+  int max_guidance_period; /* P: chained guided steps kept alive for transform_guidance */
+} dd_config;
+
+typedef struct dd_sampler_params {
+  float guidance_scale;   /* classifier-free guidance scale (--guidance_scale) */
+  float gs, ls;           /* global / local prototype energy weights (--gs, --ls) */
+  float rho;              /* guidance step size (--rho) */
+  float constraint_value; /* L-inf radius (--constraint_value) */
+  int use_global, use_local; /* --optimize_targets "global_prototype-local_prototype" */
+  int guidance_period;    /* score divisor (args.guidance_period, generate_data.py:719) */
+} dd_sampler_params;
+
+typedef struct dd_expand_args {
+  const float* image_latents; /* [B,4,L,L] */
+  const float* noise;         /* [B,4,L,L] */
+  const float* e;             /* [B,4] channel_noise  ~ U[0,1)   (transform guidance) */
+  const float* b;             /* [B,4] channel bias   ~ N(0,1) */
+  const int* targets;         /* [B] int32 class ids */
+  int B;
+  int start_index;            /* int((1-strength)*n_steps), generate_data.py:1174 */
+  int guidance_type;          /* 0 none, 1 transform_guidance, 2 direct_guidance */
+  int guide_first, guide_count; /* guide_timesteps = timesteps[guide_first : guide_first+guide_count] (:1178) */
+  float* z_out;               /* [B,4,L,L] final latents */
+  float* image_out;           /* [B,3,8L,8L] in [0,1] (may be NULL) */
+  float* score_out;           /* [1] device scalar: last guidance score (may be NULL) */
+} dd_expand_args;
+
+int dd_create(const dd_config* cfg, dd_engine** out);
+void dd_destroy(dd_engine* e);
+const char* dd_last_error(dd_engine* e);
+
+/* model: "unet" | "vae" | "guide"; key: Hugging Face / timm state-dict key; data: HOST fp32 */
+int dd_load_tensor(dd_engine* e, const char* model, const char* key, const float* data, int ndim, const int64_t* shape);
+int dd_finalize_weights(dd_engine* e);
+
+/* timesteps: host int32[n] (descending, e.g. 981..1); alphas_cumprod: host float[num_train]; */
+int dd_set_schedule(dd_engine* e, const int* timesteps, int n, const float* alphas_cumprod, int num_train_timesteps,
+                    float final_alpha_cumprod, const dd_sampler_params* sp);
+/* Pc [C,D], Pg [C,K,D] HOST fp32, already L2-normalised by the caller as the reference does */
+int dd_set_prototypes(dd_engine* e, const float* Pc, const float* Pg, int C, int K, int D);
+/* embeds: DEVICE fp32 [2B, text_len, cross_dim], negative half first */
+int dd_set_prompt(dd_engine* e, const float* embeds, int B, void* stream);
+
+int dd_add_noise(dd_engine* e, const float* x, const float* noise, float* out, int B, int step_index, void* stream);
+int dd_denoise_step(dd_engine* e, const float* z, int step_index, float* z_prev_out, float* x0_out, int B, void* stream);
+int dd_transform_guidance(dd_engine* e, const float* z, const int* targets, const float* ch_e, const float* ch_b,
+                          int first_step_index, int P, float* z_out, float* score_out, float* grad_eb_out, int B,
+                          void* stream);
+int dd_direct_guidance(dd_engine* e, const float* z, const int* targets, int step_index, float* z_next_out, float* x0_out,
+                       float* score_out, float* grad_z_out, int B, void* stream);
+int dd_decode(dd_engine* e, const float* z, float* image_out, int denormalize, int B, void* stream);
+int dd_expand(dd_engine* e, const dd_expand_args* a, void* stream);
+/* images: DEVICE fp32 [B,3,S,S] (S = guide_input_size) -> feats DEVICE fp32 [B, D] */
+int dd_guide_encode(dd_engine* e, const float* images, float* feats, int B, void* stream);
+/* diagnostic: raw UNet forward, eps2_out DEVICE fp32 [2B,4,L,L] (uncond half first) */
+int dd_unet_forward(dd_engine* e, const float* z, int step_index, float* eps2_out, int B, void* stream);
+
+/* per-module VJP diagnostics (parity of the hand-derived reverse programs vs torch.autograd.grad, generate_data.py:721/761):
+ *   g_z = J_unet(z)^T g_eps2 ; g_z = J_decode(z)^T g_image ; g_images = J_guide(images)^T g_feats */
+int dd_unet_vjp(dd_engine* e, const float* z, int step_index, const float* g_eps2, float* g_z_out, int B, void* stream);
+int dd_decode_vjp(dd_engine* e, const float* z, const float* g_image, float* g_z_out, int B, void* stream);
+int dd_guide_vjp(dd_engine* e, const float* images, const float* g_feats, float* g_images_out, int B, void* stream);
+
+size_t dd_workspace_bytes(dd_engine* e);
+/* algorithmic MFMA-eligible FLOPs (conv/linear/attention, 2 per MAC) enqueued since the last call */
+double dd_flops_last(dd_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

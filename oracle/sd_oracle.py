@@ -1,0 +1,417 @@
+"""CPU ORACLE — test infrastructure only (never imported by the product path).
+
+A plain torch fp32 CPU restatement of the hot path of haoweiz23/DistDiff `generate_data.py`:
+the DDIM denoising loop with classifier-free guidance and hierarchical (class + group prototype)
+energy guidance. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+PARITY STATUS: **parity unpinned for the third-party arithmetic.** The reference ships no golden vectors
+or known-answer tests and its arithmetic lives in diffusers / timm / torchvision, none of
+which is installed here nor vendored under /root/reference, so the UNet / VAE / ResNet-50 / DDIM modules
+below restate the *published* diffusers-0.28 / timm / SD-v1 config definitions.
+What IS pinned: the reference's own hot-path functions (`denoise_one_step`, `transform_guidance`,
+`direct_guidance`, `tensor_clamp`, `linfball_proj`) are executed from /root/reference by
+tests/golden/make_fixtures.py against this oracle's model objects (duck-typed like the diffusers objects)
+and the committed fixtures tests/golden/*.pt hold their outputs; tests/test_oracle.py checks the restated
+sampler below against those fixtures, and every primitive against torch.nn.functional.
+
+Reference lines restated (file:line in /root/reference):
+  denoise_one_step        generate_data.py:109-121
+  tensor_clamp / linfball generate_data.py:124-137
+  transform_guidance      generate_data.py:687-732
+  direct_guidance         generate_data.py:735-767
+  main denoise loop       generate_data.py:1161-1228
+  encode_image            model_utils.py:29-41   (forward_features -> AdaptiveAvgPool2d(1) -> flatten)
+  shard ranges            generate_data.py:1003-1007
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from distdiff_amd.config import EngineConfig
+
+
+# ------------------------------------------------------------------------------------------------
+# DDIMScheduler (diffusers, SD-v1 scheduler_config.json) — SURVEY.md row A3
+# ------------------------------------------------------------------------------------------------
+class DDIMSchedulerOracle:
+    def __init__(self, cfg):
+        s = cfg.scheduler if isinstance(cfg, EngineConfig) else cfg
+        self.cfg = s
+        T = s.num_train_timesteps
+        if s.beta_schedule == "scaled_linear":
+            betas = torch.linspace(s.beta_start ** 0.5, s.beta_end ** 0.5, T, dtype=torch.float32) ** 2
+        elif s.beta_schedule == "linear":
+            betas = torch.linspace(s.beta_start, s.beta_end, T, dtype=torch.float32)
+        else:
+            raise NotImplementedError(s.beta_schedule)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if s.set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = None
+
+    def set_timesteps(self, n):
+        s = self.cfg
+        self.num_inference_steps = n
+        assert s.timestep_spacing == "leading"
+        ratio = s.num_train_timesteps // n
+        ts = (torch.arange(0, n) * ratio).round().flip(0).to(torch.int64) + s.steps_offset
+        self.timesteps = ts
+        return ts
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def coefficients(self, t):
+        t = int(t)
+        prev = t - self.cfg.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        return a_t, a_p
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        a_t, a_p = self.coefficients(timestep)
+        beta_t = 1 - a_t
+        x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5
+        direction = (1 - a_p) ** 0.5 * model_output          # eta = 0 -> std_dev_t = 0
+        prev = a_p ** 0.5 * x0 + direction
+        return {"prev_sample": prev, "pred_original_sample": x0}
+
+    def add_noise(self, original, noise, timesteps):
+        a = self.alphas_cumprod[int(timesteps)]
+        return a ** 0.5 * original + (1 - a) ** 0.5 * noise
+
+
+# ------------------------------------------------------------------------------------------------
+# UNet2DConditionModel (SD-1.x topology) — SURVEY.md row A2
+# ------------------------------------------------------------------------------------------------
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def _resnet(sd, p, x, temb, groups, eps):
+    h = F.silu(F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps))
+    h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    if temb is not None:
+        t = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
+        h = h + t[:, :, None, None]
+    h = F.silu(F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps))
+    h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
+    return x + h
+
+
+def _attention(sd, p, x, ctx, heads):
+    B, N, Cc = x.shape
+    q = F.linear(x, sd[p + ".to_q.weight"], sd.get(p + ".to_q.bias"))
+    k = F.linear(ctx, sd[p + ".to_k.weight"], sd.get(p + ".to_k.bias"))
+    v = F.linear(ctx, sd[p + ".to_v.weight"], sd.get(p + ".to_v.bias"))
+    d = Cc // heads
+    q, k, v = (t.reshape(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = o.transpose(1, 2).reshape(B, N, Cc)
+    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+
+
+def _transformer(sd, p, x, ctx, heads, groups):
+    B, Cc, H, W = x.shape
+    res = x
+    h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    t = p + ".transformer_blocks.0"
+    n = F.layer_norm(h, (Cc,), sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], 1e-5)
+    h = h + _attention(sd, t + ".attn1", n, n, heads)
+    n = F.layer_norm(h, (Cc,), sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], 1e-5)
+    h = h + _attention(sd, t + ".attn2", n, ctx, heads)
+    n = F.layer_norm(h, (Cc,), sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], 1e-5)
+    proj = F.linear(n, sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
+    hid, gate = proj.chunk(2, dim=-1)
+    ff = F.linear(hid * F.gelu(gate), sd[t + ".ff.net.2.weight"], sd[t + ".ff.net.2.bias"])
+    h = h + ff
+    h = h.reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    h = F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    return h + res
+
+
+class UNetOracle:
+    """Callable like diffusers' UNet2DConditionModel: unet(x, t, encoder_hidden_states, return_dict=False)[0]."""
+
+    def __init__(self, cfg: EngineConfig, sd):
+        self.cfg, self.sd = cfg, sd
+
+    def __call__(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=False, **kw):
+        u, sd = self.cfg.unet, self.sd
+        g, eps, heads = u.norm_num_groups, u.norm_eps, u.num_heads
+        B = sample.shape[0]
+        t = torch.as_tensor(timestep).reshape(-1).expand(B)
+        temb = timestep_embedding(t, u.block_out_channels[0], u.flip_sin_to_cos, u.freq_shift)
+        temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+        temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+        h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+        skips = [h]
+        nlev = len(u.block_out_channels)
+        for i in range(nlev):
+            for j in range(u.layers_per_block):
+                h = _resnet(sd, "down_blocks.%d.resnets.%d" % (i, j), h, temb, g, eps)
+                if u.down_attn[i]:
+                    h = _transformer(sd, "down_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, heads, g)
+                skips.append(h)
+            if i < nlev - 1:
+                p = "down_blocks.%d.downsamplers.0.conv" % i
+                h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=1)
+                skips.append(h)
+        h = _resnet(sd, "mid_block.resnets.0", h, temb, g, eps)
+        h = _transformer(sd, "mid_block.attentions.0", h, encoder_hidden_states, heads, g)
+        h = _resnet(sd, "mid_block.resnets.1", h, temb, g, eps)
+        for i in range(nlev):
+            for j in range(u.layers_per_block + 1):
+                h = torch.cat([h, skips.pop()], dim=1)
+                h = _resnet(sd, "up_blocks.%d.resnets.%d" % (i, j), h, temb, g, eps)
+                if u.up_attn[i]:
+                    h = _transformer(sd, "up_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, heads, g)
+            if i < nlev - 1:
+                p = "up_blocks.%d.upsamplers.0.conv" % i
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+                h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+        h = F.silu(F.group_norm(h, g, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
+        h = F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+        return (h,)
+
+
+# ------------------------------------------------------------------------------------------------
+# AutoencoderKL.decode — SURVEY.md row A4
+# ------------------------------------------------------------------------------------------------
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class VAEOracle:
+    def __init__(self, cfg: EngineConfig, sd):
+        self.cfg, self.sd = cfg, sd
+        self.config = _Cfg(scaling_factor=cfg.vae.scaling_factor)
+
+    def decode(self, z, return_dict=False, generator=None):
+        v, sd = self.cfg.vae, self.sd
+        g, eps = v.norm_num_groups, v.norm_eps
+        h = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+        h = F.conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+        h = _resnet(sd, "decoder.mid_block.resnets.0", h, None, g, eps)
+        a = "decoder.mid_block.attentions.0"
+        B, Cc, H, W = h.shape
+        n = F.group_norm(h, g, sd[a + ".group_norm.weight"], sd[a + ".group_norm.bias"], eps)
+        n = n.reshape(B, Cc, H * W).transpose(1, 2)
+        o = _attention(sd, a, n, n, 1)
+        h = h + o.transpose(1, 2).reshape(B, Cc, H, W)
+        h = _resnet(sd, "decoder.mid_block.resnets.1", h, None, g, eps)
+        nlev = len(v.block_out_channels)
+        for i in range(nlev):
+            for j in range(v.layers_per_block + 1):
+                h = _resnet(sd, "decoder.up_blocks.%d.resnets.%d" % (i, j), h, None, g, eps)
+            if i < nlev - 1:
+                p = "decoder.up_blocks.%d.upsamplers.0.conv" % i
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+                h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+        h = F.silu(F.group_norm(h, g, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps))
+        h = F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+        return (h,)
+
+
+class ImageProcessorOracle:
+    """VaeImageProcessor.postprocess(output_type='pt'): denormalize = (x/2+0.5).clamp(0,1) — row A5."""
+
+    def postprocess(self, image, output_type="pt", do_denormalize=None):
+        if do_denormalize is None:
+            do_denormalize = [True] * image.shape[0]
+        return torch.stack([(image[i] / 2 + 0.5).clamp(0, 1) if do_denormalize[i] else image[i] for i in range(image.shape[0])])
+
+
+# ------------------------------------------------------------------------------------------------
+# timm resnet50 + model_utils.add_encoder_image_method (eval-mode BN) — SURVEY.md row A7
+# ------------------------------------------------------------------------------------------------
+class GuideOracle:
+    def __init__(self, cfg: EngineConfig, sd):
+        self.cfg, self.sd = cfg, sd
+
+    def _bn(self, x, p):
+        sd = self.sd
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0,
+                            self.cfg.guide.bn_eps)
+
+    def forward_features(self, x):
+        g, sd = self.cfg.guide, self.sd
+        x = F.relu(self._bn(F.conv2d(x, sd["conv1.weight"], None, stride=2, padding=3), "bn1"))
+        x = F.max_pool2d(x, 3, 2, 1)
+        for li, nb in enumerate(g.blocks):
+            for bi in range(nb):
+                p = "layer%d.%d" % (li + 1, bi)
+                stride = 2 if (bi == 0 and li > 0) else 1
+                sc = x
+                o = F.relu(self._bn(F.conv2d(x, sd[p + ".conv1.weight"]), p + ".bn1"))
+                o = F.relu(self._bn(F.conv2d(o, sd[p + ".conv2.weight"], stride=stride, padding=1), p + ".bn2"))
+                o = self._bn(F.conv2d(o, sd[p + ".conv3.weight"]), p + ".bn3")
+                if (p + ".downsample.0.weight") in sd:
+                    sc = self._bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), p + ".downsample.1")
+                x = F.relu(o + sc)
+        return x
+
+    def encode_image(self, x, pooling="avg"):
+        f = self.forward_features(x)
+        f = F.adaptive_avg_pool2d(f, (1, 1)) if pooling == "avg" else F.adaptive_max_pool2d(f, (1, 1))
+        return torch.flatten(f, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampler: restatement of generate_data.py:109-137, 687-767, 1161-1228
+# ------------------------------------------------------------------------------------------------
+class SamplerArgs:
+    """The subset of the reference's module-global `args` the hot path reads."""
+
+    def __init__(self, **kw):
+        self.do_classifier_free_guidance = True
+        self.guidance_scale = 7.5
+        self.gs = 1.0
+        self.ls = 1.0
+        self.rho = 10.0
+        self.guidance_period = 2
+        self.guidance_step = 20
+        self.constraint_value = 0.2
+        self.strength = 0.5
+        self.guidance_type = "transform_guidance"
+        self.num_inference_steps = 50
+        self.__dict__.update(kw)
+
+
+def denoise_one_step(args, latents, scheduler, t, unet, prompt_embeds):
+    """generate_data.py:109-121."""
+    x = torch.cat([latents] * 2) if args.do_classifier_free_guidance else latents
+    x = scheduler.scale_model_input(x, t)
+    noise_pred = unet(x, t, prompt_embeds, class_labels=None, return_dict=False)[0]
+    if args.do_classifier_free_guidance:
+        u, c = noise_pred.chunk(2)
+        noise_pred = u + args.guidance_scale * (c - u)
+    out = scheduler.step(noise_pred, t, latents, return_dict=True)
+    return out["prev_sample"], out["pred_original_sample"]
+
+
+def energy(args, feats, targets, global_proto, local_proto):
+    """generate_data.py:707-717 / 749-759."""
+    score = 0.0
+    if global_proto is not None:
+        gp = global_proto[targets]
+        score = score + torch.norm(feats - gp, dim=1, p=2).mean() * args.gs
+    if local_proto is not None:
+        lp = local_proto[targets]
+        idx = torch.argmax(torch.bmm(feats.unsqueeze(1), lp.permute(0, 2, 1)), -1)
+        lp = lp[torch.arange(lp.size(0)), idx.squeeze(-1)]
+        score = score + torch.norm(feats - lp, dim=1, p=2).mean() * args.ls
+    return score
+
+
+def _guide_features(vae, guide, x0, size):
+    img = vae.decode(x0 / vae.config.scaling_factor)[0]          # postprocess(do_denormalize=False) is the identity
+    img = F.interpolate(img, size=(size, size), mode="bicubic")
+    return guide.encode_image(img).float()
+
+
+def transform_guidance(args, latents, targets, sub_timesteps, scheduler, unet, prompt_embeds, vae, guide, e, b,
+                       global_proto, local_proto, guide_size=224):
+    """generate_data.py:687-732 with the random draws (e ~ U[0,1), b ~ N(0,1), :692-695) passed in explicitly."""
+    e = e.clone().requires_grad_(True)
+    b = b.clone().requires_grad_(True)
+    x = latents * (1 + e) + b
+    score = 0.0
+    for t in sub_timesteps:
+        x, x0 = denoise_one_step(args, x, scheduler, t, unet, prompt_embeds)
+        feats = _guide_features(vae, guide, x0, guide_size)
+        score = score + energy(args, feats, targets, global_proto, local_proto)
+    score = score / args.guidance_period
+    ge, gb = torch.autograd.grad(score, [e, b])
+    e2 = e.detach() - args.rho * ge
+    b2 = b.detach() - args.rho * gb
+    new = latents * (1 + e2) + b2
+    lo, hi = latents - args.constraint_value, latents + args.constraint_value
+    new = torch.where(new < lo, lo, new)        # tensor_clamp: lower bound first, then upper (:129-132)
+    new = torch.where(new > hi, hi, new)
+    return new.detach(), score.detach(), (ge, gb)
+
+
+def direct_guidance(args, latents, targets, t, scheduler, unet, prompt_embeds, vae, guide, global_proto, local_proto,
+                    guide_size=224):
+    """generate_data.py:735-767."""
+    z = latents.clone().requires_grad_(True)
+    z_next, x0 = denoise_one_step(args, z, scheduler, t, unet, prompt_embeds)
+    feats = _guide_features(vae, guide, x0, guide_size)
+    feats = feats / feats.norm(dim=-1, keepdim=True)
+    score = energy(args, feats, targets, global_proto, local_proto)
+    (g,) = torch.autograd.grad(score, z)
+    z_next = z_next - args.rho * g
+    return z_next.detach(), x0.detach(), score.detach(), g
+
+
+def start_index(strength, n):
+    return int((1 - strength) * n)          # generate_data.py:1174
+
+
+def guide_timesteps(timesteps, guidance_step, guidance_period):
+    n = len(timesteps)
+    return [int(t) for t in timesteps[n - guidance_step: n - guidance_step + guidance_period]]   # :1178
+
+
+def shard_range(total, total_split, split):
+    """generate_data.py:1003-1007."""
+    per = math.ceil(total / total_split)
+    if split == total_split - 1 and total < per * (split + 1):
+        return list(range(per * split, total))
+    return list(range(per * split, per * (split + 1)))
+
+
+def expand_one(args, cfg, models, image_latents, noise, e, b, prompt_embeds, neg_embeds, targets, global_proto, local_proto,
+               trace=None):
+    """One (batch, expand-index) of the main loop, generate_data.py:1161-1228. Returns (final latents, image in [0,1], score)."""
+    unet, vae, guide, sched = models
+    timesteps = sched.set_timesteps(args.num_inference_steps)
+    si = start_index(args.strength, len(timesteps))
+    z = sched.add_noise(image_latents, noise, timesteps[si])
+    gts = guide_timesteps(timesteps, args.guidance_step, args.guidance_period) if args.guidance_type else []
+    embeds = torch.cat([neg_embeds, prompt_embeds]) if args.do_classifier_free_guidance else prompt_embeds
+    score = None
+    gsz = cfg.guide.input_size
+    for t in timesteps[si:]:
+        t = int(t)
+        if gts and t == gts[0] and args.guidance_type == "transform_guidance":
+            if trace is not None:
+                trace.append(("transform_guidance", t))
+            z, score, _ = transform_guidance(args, z, targets, gts, sched, unet, embeds, vae, guide, e, b, global_proto,
+                                             local_proto, gsz)
+            with torch.no_grad():
+                z, _ = denoise_one_step(args, z, sched, t, unet, embeds)
+            if trace is not None:
+                trace.append(("denoise", t))
+        elif gts and t in gts and args.guidance_type == "direct_guidance":
+            if trace is not None:
+                trace.append(("direct_guidance", t))
+            z, _, score, _ = direct_guidance(args, z, targets, t, sched, unet, embeds, vae, guide, global_proto, local_proto, gsz)
+        else:
+            if trace is not None:
+                trace.append(("denoise", t))
+            with torch.no_grad():
+                z, _ = denoise_one_step(args, z, sched, t, unet, embeds)
+    with torch.no_grad():
+        img = vae.decode(z / vae.config.scaling_factor)[0]
+        img = (img / 2 + 0.5).clamp(0, 1)
+    return z, img, score
+
+
+def build_models(cfg, weights):
+    return (UNetOracle(cfg, weights["unet"]), VAEOracle(cfg, weights["vae"]), GuideOracle(cfg, weights["guide"]),
+            DDIMSchedulerOracle(cfg))
