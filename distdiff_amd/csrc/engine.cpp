@@ -122,6 +122,26 @@ struct Program {
   }
 };
 
+struct Profiler {   // HIP-event timing of every op, by kernel family (dd_profile_*)
+  enum { CONV = 0, ATTN = 1, NORM = 2, OTHER = 3, NFAM = 4 };
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Rec { int fam; double flops; size_t e0; };
+  std::vector<Rec> recs;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+  }
+  void begin(int fam, double flops, hipStream_t s) {
+    if (!on) return;
+    Rec r; r.fam = fam; r.flops = flops; r.e0 = used;
+    hipEventRecord(get(), s); get();
+    recs.push_back(r);
+  }
+  void end(hipStream_t s) { if (on) hipEventRecord(pool[recs.back().e0 + 1], s); }
+};
+
 struct Ctx {  // per-call execution context
   char* act = nullptr;   // activation slab of the instance being run
   char* grad = nullptr;  // shared gradient slab
@@ -133,6 +153,7 @@ struct Ctx {  // per-call execution context
   hipStream_t s = nullptr;
   const std::vector<std::pair<bf16_t*, bf16_t*>>* cross_kv = nullptr;  // per cross-attention slot
   double* flops = nullptr;
+  Profiler* prof = nullptr;
 };
 
 inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
@@ -182,6 +203,7 @@ struct dd_engine {
   float* score_tmp = nullptr;
   size_t total_bytes = 0;
   double flops = 0;
+  Profiler prof;
 
   void* dmalloc(size_t bytes, bool zero = true) {
     void* p = nullptr;
@@ -428,6 +450,9 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
   if (op_end < 0) op_end = (int)P.ops.size();
   for (int i = op_begin; i < op_end; ++i) {
     const Op& op = P.ops[i];
+    const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
+                    : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
+    if (c.prof) c.prof->begin(fam, (op.kind == OP_CONV || op.kind == OP_ATTN) ? op.flops : 0.0, c.s);
     switch (op.kind) {
       case OP_CONV: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
@@ -492,12 +517,17 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
       } break;
       case OP_GAP: break;
     }
+    if (c.prof) c.prof->end(c.s);
   }
 }
 
 void run_bwd(const Program& P, const Ctx& c) {
   for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
     const Op& op = P.ops[i];
+    const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
+                    : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
+    if (c.prof) c.prof->begin(fam, op.kind == OP_CONV ? op.flops : op.kind == OP_ATTN ? op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5) : 0.0, c.s);
+    struct EndGuard { const Ctx& c; ~EndGuard() { if (c.prof) c.prof->end(c.s); } } _guard{c};
     switch (op.kind) {
       case OP_CONV: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
@@ -777,7 +807,7 @@ struct Run {
   dd_engine* E; hipStream_t s; int B;
   Ctx ctx(const Program&, char* act) {
     Ctx c; c.act = act; c.grad = E->grad_slab; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
-    c.scratch_tmp = E->scratch_tmp; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops;
+    c.scratch_tmp = E->scratch_tmp; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
     return c;
   }
 };
@@ -1281,6 +1311,28 @@ int dd_guide_vjp(dd_engine* E, const float* images, const float* g_feats, float*
     HIPCHK(launch_gap_bwd(g_feats, grad_ptr(gc, f), f.ld, B, f.H * f.W, f.C, nullptr, 0, s));
     run_bwd(E->guide, gc);
     HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(gc, gin), 0, g_images_out, B, 3, gin.H, gin.W, gin.ld, 1.f, 0.f, 0, 0.f, 0.f, s));
+  });
+}
+
+int dd_profile_enable(dd_engine* E, int on) {
+  if (!E) return DD_ERR_ARG;
+  E->prof.on = on != 0;
+  E->prof.used = 0;
+  E->prof.recs.clear();
+  return DD_OK;
+}
+// out[fam*3 + {0,1,2}] = {total ms, algorithmic flops, launches(op count)} for fam in {conv_gemm, attention, norm, other}
+int dd_profile_read(dd_engine* E, double* out12) {
+  if (!E || !out12) return DD_ERR_ARG;
+  DD_TRY(E, {
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < 12; ++i) out12[i] = 0;
+    for (auto& r : E->prof.recs) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, E->prof.pool[r.e0], E->prof.pool[r.e0 + 1]));
+      out12[r.fam * 3 + 0] += ms; out12[r.fam * 3 + 1] += r.flops; out12[r.fam * 3 + 2] += 1;
+    }
+    E->prof.used = 0; E->prof.recs.clear();
   });
 }
 

@@ -67,6 +67,8 @@ def _declare(l):
     l.dd_unet_vjp.argtypes = [vp, vp, i, vp, vp, i, vp]
     l.dd_decode_vjp.argtypes = [vp, vp, vp, vp, i, vp]
     l.dd_guide_vjp.argtypes = [vp, vp, vp, vp, i, vp]
+    l.dd_profile_enable.argtypes = [vp, i]
+    l.dd_profile_read.argtypes = [vp, vp]
     l.dd_workspace_bytes.argtypes = [vp]
     l.dd_workspace_bytes.restype = C.c_size_t
     l.dd_flops_last.argtypes = [vp]
@@ -268,6 +270,15 @@ class Engine:
         out = torch.empty_like(x)
         self._chk(self.L.dd_guide_vjp(self._h, _p(x), _p(g), _p(out), x.shape[0], _stream()), "dd_guide_vjp")
         return out
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.dd_profile_enable(self._h, int(on)), "dd_profile_enable")
+
+    def profile_read(self):
+        out = (C.c_double * 12)()
+        self._chk(self.L.dd_profile_read(self._h, out), "dd_profile_read")
+        names = ["conv_gemm", "attention", "norm", "other"]
+        return {n: {"ms": out[3 * k], "flops": out[3 * k + 1], "ops": int(out[3 * k + 2])} for k, n in enumerate(names)}
 
     def workspace_bytes(self):
         return int(self.L.dd_workspace_bytes(self._h))

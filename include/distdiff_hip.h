@@ -126,6 +126,11 @@ int dd_unet_vjp(dd_engine* e, const float* z, int step_index, const float* g_eps
 int dd_decode_vjp(dd_engine* e, const float* z, const float* g_image, float* g_z_out, int B, void* stream);
 int dd_guide_vjp(dd_engine* e, const float* images, const float* g_feats, float* g_images_out, int B, void* stream);
 
+/* live HIP-event timing of every enqueued op on the caller's stream, by kernel family
+ * (0 conv_gemm, 1 attention, 2 norm, 3 other): out12[fam*3 + {0,1,2}] = {ms, algorithmic FLOPs, ops}. dd_profile_read synchronises. */
+int dd_profile_enable(dd_engine* e, int on);
+int dd_profile_read(dd_engine* e, double* out12);
+
 size_t dd_workspace_bytes(dd_engine* e);
 /* algorithmic MFMA-eligible FLOPs (conv/linear/attention, 2 per MAC) enqueued since the last call */
 double dd_flops_last(dd_engine* e);
