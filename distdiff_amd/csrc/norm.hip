@@ -2,7 +2,7 @@
 // Replaces torch.nn.GroupNorm / F.silu / LayerNorm inside diffusers' ResnetBlock2D, Transformer2DModel,
 // AutoencoderKL decoder (reference call sites generate_data.py:112, :701) and their autograd backward (:721).
 // HBM-bound: 16-byte vector loads, fp32 statistics, deterministic two-stage reductions (no float atomics
-// to global memory, so results are bitwise reproducible run to run).
+// anywhere, so results are bitwise reproducible run to run).
 #include "common.h"
 #include "kernels.h"
 
@@ -22,13 +22,12 @@ __host__ __device__ inline int gn_split(int HW) {
 // Pass 1 (bwd): per (b, split, group) partial (s1 = sum dxhat, s2 = sum dxhat*xhat).
 template <bool BWD>
 __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GroupNormParams p) {
-  extern __shared__ float sh[];  // [2][C]
+  // sh[r][2][C]: per staging-row partial sums, combined in a fixed order (no atomics: bitwise reproducible)
+  extern __shared__ float sh[];
   const int C = p.C, G = p.G, cpg = C / G, VC = C >> 3;
   const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x;
   const int rows_per = (p.HW + S - 1) / S;
   const int row_begin = s * rows_per, row_end = min(p.HW, row_begin + rows_per);
-  for (int c = threadIdx.x; c < 2 * C; c += GN_THREADS) sh[c] = 0.f;
-  __syncthreads();
   const int VCt = min(VC, GN_THREADS);
   const int R = GN_THREADS / VCt;
   const int my_r = threadIdx.x / VCt, my_vc0 = threadIdx.x % VCt;
@@ -66,17 +65,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GroupNormParams 
           }
         }
       }
+      float* dst = sh + (size_t)my_r * 2 * C;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sh[vc * 8 + e], a0[e]);       // LDS float add
-        atomicAdd(&sh[C + vc * 8 + e], a1[e]);
-      }
+      for (int e = 0; e < 8; ++e) { dst[vc * 8 + e] = a0[e]; dst[C + vc * 8 + e] = a1[e]; }
     }
   }
   __syncthreads();
   for (int g = threadIdx.x; g < G; g += GN_THREADS) {
     float t0 = 0.f, t1 = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { t0 += sh[c]; t1 += sh[C + c]; }
+    for (int r = 0; r < R; ++r) {
+      const float* src = sh + (size_t)r * 2 * C;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { t0 += src[c]; t1 += src[C + c]; }
+    }
     float* out = p.scratch + (((size_t)b * S + s) * G + g) * 3;
     if (!BWD) {
       const float n = (float)(row_end - row_begin) * cpg;
@@ -266,6 +266,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LayerNormParams p) {
 
 size_t groupnorm_scratch_bytes(int B, int G) { return (size_t)B * GN_MAX_SPLIT * G * 3 * sizeof(float); }
 
+static size_t gn_partial_lds(int C) {
+  const int VC = C / 8, VCt = VC < GN_THREADS ? VC : GN_THREADS, R = GN_THREADS / VCt;
+  return (size_t)R * 2 * C * sizeof(float);
+}
 static hipError_t gn_check(const GroupNormParams& p) {
   if (p.C % 8 || p.C % p.G || (p.x_ld & 7)) return hipErrorInvalidValue;
   return hipSuccess;
@@ -274,7 +278,7 @@ static hipError_t gn_check(const GroupNormParams& p) {
 hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream) {
   if (gn_check(p) != hipSuccess || (p.y_ld & 7)) return hipErrorInvalidValue;
   const int S = gn_split(p.HW);
-  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(S, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p);
+  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
   int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
   if (ablocks < 1) ablocks = 1;
   if (ablocks > 512) ablocks = 512;
@@ -285,7 +289,7 @@ hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream) {
 hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream) {
   if (gn_check(p) != hipSuccess || (p.dy_ld & 7) || (p.dx_ld & 7)) return hipErrorInvalidValue;
   const int S = gn_split(p.HW);
-  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(S, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p);
+  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
   int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
   if (ablocks < 1) ablocks = 1;
   if (ablocks > 512) ablocks = 512;

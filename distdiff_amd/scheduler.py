@@ -11,13 +11,14 @@ class DDIMSchedule:
         self.cfg = cfg or SchedulerConfig()
         c = self.cfg
         T = c.num_train_timesteps
+        import torch  # same fp32 linspace / cumprod arithmetic as diffusers' DDIMScheduler.__init__ (host-side table only)
         if c.beta_schedule == "scaled_linear":
-            betas = np.linspace(np.float32(c.beta_start) ** 0.5, np.float32(c.beta_end) ** 0.5, T, dtype=np.float32) ** 2
+            betas = torch.linspace(c.beta_start ** 0.5, c.beta_end ** 0.5, T, dtype=torch.float32) ** 2
         elif c.beta_schedule == "linear":
-            betas = np.linspace(c.beta_start, c.beta_end, T, dtype=np.float32)
+            betas = torch.linspace(c.beta_start, c.beta_end, T, dtype=torch.float32)
         else:
             raise NotImplementedError(c.beta_schedule)
-        self.alphas_cumprod = np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).numpy()
         self.final_alpha_cumprod = 1.0 if c.set_alpha_to_one else float(self.alphas_cumprod[0])
         self.timesteps = None
 

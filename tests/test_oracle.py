@@ -1,0 +1,155 @@
+"""CPU tests of the oracle (test infrastructure) — the restated sampler vs fixtures produced by the REFERENCE's own
+functions (tests/golden/make_fixtures.py executes generate_data.py:109-137, 687-767 from /root/reference), plus the
+schedule / shard known answers of SURVEY.md section 8c."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from distdiff_amd.config import tiny_config
+from distdiff_amd.weights import synthetic_weights
+from oracle import sd_oracle as O
+
+FIX = os.path.join(os.path.dirname(__file__), "golden", "tiny_fixture.pt")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return torch.load(FIX, weights_only=False)
+
+
+@pytest.fixture(scope="module")
+def models():
+    cfg = tiny_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=5)
+    return cfg, w, O.build_models(cfg, w)
+
+
+def test_schedule_known_answers():
+    from distdiff_amd.config import sd15_config
+    s = O.DDIMSchedulerOracle(sd15_config())
+    ts = s.set_timesteps(50)
+    assert ts.tolist() == [981 - 20 * i for i in range(50)]
+    assert [O.start_index(x, 50) for x in (0.5, 0.9, 1.0)] == [25, 4, 0]
+    assert O.guide_timesteps(ts, 20, 2) == [381, 361]
+    a = s.alphas_cumprod
+    assert abs(float(a[0]) - 0.99915) < 1e-5 and abs(float(a[999]) - 0.0046602) < 1e-6
+    # prev of the last step (t=1) is final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one=False)
+    at, ap = s.coefficients(1)
+    assert float(ap) == float(a[0])
+
+
+def test_product_schedule_matches_oracle():
+    from distdiff_amd.config import sd15_config
+    from distdiff_amd.scheduler import DDIMSchedule, guide_window, start_index
+    p = DDIMSchedule(sd15_config().scheduler)
+    o = O.DDIMSchedulerOracle(sd15_config())
+    assert p.set_timesteps(50) == o.set_timesteps(50).tolist()
+    assert torch.allclose(torch.from_numpy(p.alphas_cumprod), o.alphas_cumprod, rtol=1e-6, atol=0)
+    assert guide_window(50, 20, 2) == (30, 2) and p.timesteps[30:32] == [381, 361]
+    assert start_index(0.5, 50) == 25
+
+
+def test_shard_ranges_match_reference_formula():
+    from distdiff_amd.launcher import shard_range
+    for total, nsplit in [(9144, 4), (9144, 8), (8, 8), (10, 4), (1, 1)]:
+        per = -(-total // nsplit)
+        got = [shard_range(total, nsplit, s) for s in range(nsplit)]
+        assert got == [O.shard_range(total, nsplit, s) for s in range(nsplit)]
+        flat = [i for r in got for i in r if i < total]
+        assert sorted(set(flat)) == list(range(total))
+        assert all(len(r) <= per for r in got)
+
+
+def test_reference_denoise_one_step(fx, models):
+    cfg, w, (unet, vae, guide, sched) = models
+    sched.set_timesteps(fx["n_steps"])
+    args = O.SamplerArgs(**fx["args"])
+    emb = torch.cat([fx["negative_embeds"], fx["prompt_embeds"]])
+    with torch.no_grad():
+        zp, x0 = O.denoise_one_step(args, fx["z"], sched, fx["guide_timesteps"][0], unet, emb)
+    assert torch.allclose(zp, fx["ref_denoise_z_prev"], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x0, fx["ref_denoise_x0"], rtol=1e-5, atol=1e-5)
+
+
+def test_reference_transform_guidance(fx, models):
+    cfg, w, (unet, vae, guide, sched) = models
+    sched.set_timesteps(fx["n_steps"])
+    args = O.SamplerArgs(**fx["args"])
+    emb = torch.cat([fx["negative_embeds"], fx["prompt_embeds"]])
+    z, score, _ = O.transform_guidance(args, fx["z"], fx["targets"], fx["guide_timesteps"], sched, unet, emb, vae, guide, fx["e"], fx["b"],
+                                       fx["Pc"], fx["Pg"], cfg.guide.input_size)
+    assert abs(float(score) - float(fx["ref_transform_score"])) < 1e-4
+    assert torch.allclose(z, fx["ref_transform_z"], rtol=1e-4, atol=1e-4)
+    # quirk 7: the result sits inside the L-inf ball around the input latent
+    assert float((z - fx["z"]).abs().max()) <= args.constraint_value + 1e-6
+
+
+def test_reference_direct_guidance(fx, models):
+    cfg, w, (unet, vae, guide, sched) = models
+    sched.set_timesteps(fx["n_steps"])
+    args = O.SamplerArgs(**fx["args"])
+    emb = torch.cat([fx["negative_embeds"], fx["prompt_embeds"]])
+    zn, x0, score, _ = O.direct_guidance(args, fx["z"], fx["targets"], fx["guide_timesteps"][0], sched, unet, emb, vae, guide, fx["Pc"],
+                                         fx["Pg"], cfg.guide.input_size)
+    assert abs(float(score) - float(fx["ref_direct_score"])) < 1e-5
+    assert torch.allclose(zn, fx["ref_direct_z_next"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(x0, fx["ref_direct_x0"], rtol=1e-5, atol=1e-5)
+
+
+def test_reference_linfball_clamp_order(fx):
+    c, t = fx["clamp_center"], fx["clamp_t"]
+    lo, hi = c - 0.2, c + 0.2
+    out = torch.where(t < lo, lo, t)
+    out = torch.where(out > hi, hi, out)
+    assert torch.equal(out, fx["ref_clamp_out"])
+
+
+def test_expand_loop_call_trace_and_vectors(fx, models):
+    cfg, w, ms = models
+    args = O.SamplerArgs(**fx["args"])
+    for gt in ("transform_guidance", "direct_guidance", None):
+        key = gt or "none"
+        a = O.SamplerArgs(**{**fx["args"], "guidance_type": gt})
+        tr = []
+        z, img, s = O.expand_one(a, cfg, ms, fx["lat"], fx["noise"], fx["e"], fx["b"], fx["prompt_embeds"], fx["negative_embeds"],
+                                 fx["targets"], fx["Pc"], fx["Pg"], trace=tr)
+        assert tr == fx["expand_%s_trace" % key]
+        assert torch.allclose(z, fx["expand_%s_z" % key], rtol=1e-4, atol=1e-4)
+        u8 = (img * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+        assert (u8.int() - fx["expand_%s_img_u8" % key].int()).abs().max() <= 1
+    # per-image call sequence of the script of record: one transform_guidance + re-run of that step, plain steps elsewhere
+    tr = fx["expand_transform_guidance_trace"]
+    assert [k for k, _ in tr].count("transform_guidance") == 1
+    i = [k for k, _ in tr].index("transform_guidance")
+    assert tr[i + 1] == ("denoise", tr[i][1])
+
+
+def test_primitives_against_torch_functional(models):
+    """Known-answer checks of the few primitives the oracle does not delegate to torch.nn.functional."""
+    t = torch.tensor([1.0, 981.0])
+    emb = O.timestep_embedding(t, 8, True, 0.0)
+    half = 4
+    freq = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half) / half)
+    ref = torch.cat([torch.cos(t[:, None] * freq), torch.sin(t[:, None] * freq)], -1)
+    assert torch.allclose(emb, ref, atol=1e-6)
+    # DDIM step algebra (eta = 0): z_prev = sqrt(a_p) x0 + sqrt(1-a_p) eps, x0 = (z - sqrt(1-a) eps)/sqrt(a)
+    cfg = models[0]
+    s = O.DDIMSchedulerOracle(cfg)
+    s.set_timesteps(50)
+    z, eps = torch.randn(2, 4, 4, 4), torch.randn(2, 4, 4, 4)
+    out = s.step(eps, 381, z)
+    a, ap = s.alphas_cumprod[381], s.alphas_cumprod[361]
+    x0 = (z - (1 - a).sqrt() * eps) / a.sqrt()
+    assert torch.allclose(out["pred_original_sample"], x0) and torch.allclose(out["prev_sample"], ap.sqrt() * x0 + (1 - ap).sqrt() * eps)
+    # energy: Euclidean distance to class prototype + nearest (by inner product) group prototype
+    f = torch.randn(3, 16)
+    Pc = F.normalize(torch.randn(4, 16), dim=-1)
+    Pg = F.normalize(torch.randn(4, 3, 16), dim=-1)
+    y = torch.tensor([0, 2, 3])
+    args = O.SamplerArgs(gs=1.0, ls=0.5)
+    e = O.energy(args, f, y, Pc, Pg)
+    ref = sum((f[i] - Pc[y[i]]).norm() for i in range(3)) / 3
+    ref = ref + 0.5 * sum((f[i] - Pg[y[i], int((Pg[y[i]] @ f[i]).argmax())]).norm() for i in range(3)) / 3
+    assert abs(float(e) - float(ref)) < 1e-5
