@@ -1,0 +1,269 @@
+"""Drop-in CLI for the expansion step of haoweiz23/DistDiff: same flags, defaults, shard function, resume rule and
+output layout as /root/reference/generate_data.py (parse_args :164-639, main :815-1249), with the body of the hot
+loop (:1130-1236) executed by the MI355X engine (libdistdiff_hip.so) instead of diffusers/timm/autograd.
+
+    python generate_data.py --guidance_type=transform_guidance -a resnet50 -d caltech-101 --output_dir OUT \
+        --pretrained_model_name_or_path /path/to/sd-v1-4 --K 3 --train_batch_size 1 \
+        --optimize_targets global_prototype-local_prototype --strength 0.5 --num_images_per_prompt 5 \
+        --guidance_step 20 --guidance_period 2 --encoder_weight_path ckpt.pth.tar --guidance_scale 7.5 \
+        --constraint_value 0.2 --rho 10 --total_split 4 --split 0
+
+Superset over the reference (documented, defaults reproduce it): `--steps` and `--resolution` are honoured
+(the reference parses but ignores them); `--synthetic N` runs on N seeded synthetic images with
+synthetic weights (no checkpoints / datasets are needed; used by tests and benchmarks).
+Inputs the engine does not produce yet (VAE encoder, CLIP text encoder) are read from the reference's
+own caches: `save/vae_embedding/<dataset>/<model>/image_latents.pt` and `.../text_embeds.pt`.
+"""
+import argparse
+import logging
+import math
+import os
+import sys
+
+import torch
+
+log = logging.getLogger("distdiff_amd")
+
+CUSTOM_TEMPLATE_DEFAULT = "a photo of a {}."     # dataloader.py:58 (caltech-101)
+
+# flags the reference parses (DreamBooth leftovers) and never reads on this path: accepted and ignored
+_IGNORED_VALUE_FLAGS = ["--revision", "--variant", "--dataset_name", "--dataset_config_name", "--train_data_dir", "--image_column",
+                        "--caption_column", "--tokenizer_name", "--instance_data_dir", "--class_data_dir", "--instance_prompt",
+                        "--class_prompt", "--prior_loss_weight", "--num_class_images", "--val_batch_size", "--sample_batch_size",
+                        "--num_train_epochs", "--max_train_steps", "--max_train_samples", "--checkpointing_steps",
+                        "--checkpoints_total_limit", "--resume_from_checkpoint", "--gradient_accumulation_steps", "--lr_scheduler",
+                        "--lr_warmup_steps", "--lr_num_cycles", "--lr_power", "--max_grad_norm", "--logging_dir", "--report_to",
+                        "--mixed_precision", "--prior_generation_precision", "--local_rank", "--snr_gamma", "--tokenizer_max_length",
+                        "--validation_images", "--class_labels_conditioning", "--validation_scheduler", "--dataloader_num_workers"]
+_IGNORED_BOOL_FLAGS = ["--center_crop", "--random_flip", "--with_prior_preservation", "--train_text_encoder", "--gradient_checkpointing",
+                       "--scale_lr", "--use_8bit_adam", "--allow_tf32", "--enable_xformers_memory_efficient_attention",
+                       "--set_grads_to_none", "--pre_compute_text_embeddings", "--text_encoder_use_attention_mask",
+                       "--skip_save_text_encoder", "--language_enhance", "-le"]
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="MI355X-native DistDiff data expansion (drop-in for generate_data.py)")
+    p.add_argument("--pretrained_model_name_or_path", type=str, default="CompVis/stable-diffusion-v1-4")
+    p.add_argument("--dataset", "-d", type=str, default="caltech-101")
+    p.add_argument("--arch", "-a", type=str, default="open_clip_vit_b32")
+    p.add_argument("--encoder_weight_path", type=str, default=None)
+    p.add_argument("--guidance_type", default=None)
+    p.add_argument("--constraint_value", default=0.8, type=float)
+    p.add_argument("--steps", default=50, type=int)
+    p.add_argument("--K", default=3, type=int)
+    p.add_argument("--guidance_step", default=1, type=int)
+    p.add_argument("--guidance_period", default=1, type=int)
+    p.add_argument("--total_split", default=8, type=int)
+    p.add_argument("--split", default=0, type=int)
+    p.add_argument("--num_images_per_prompt", default=4, type=int)
+    p.add_argument("--first_image_index", default=0, type=int)
+    p.add_argument("--optimize_targets", default=None, type=str)
+    p.add_argument("--rho", type=float, default=10.0)
+    p.add_argument("--gs", type=float, default=1.0)
+    p.add_argument("--ls", type=float, default=1.0)
+    p.add_argument("--strength", type=float, default=0.9)
+    p.add_argument("--cache_dir", type=str, default=None)
+    p.add_argument("--resolution", type=int, default=512)
+    p.add_argument("--text_to_img", default=False, action="store_true")
+    p.add_argument("--output_dir", type=str, default="data_expand")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--train_batch_size", type=int, default=2)
+    p.add_argument("--guidance_scale", type=float, default=7.5)
+    p.add_argument("--do_classifier_free_guidance", type=bool, default=True)   # type=bool: any string -> True, as in the reference
+    p.add_argument("--offset_noise", action="store_true", default=False)
+    for f in _IGNORED_VALUE_FLAGS:
+        p.add_argument(f, default=None, help=argparse.SUPPRESS)
+    for f in _IGNORED_BOOL_FLAGS:
+        p.add_argument(f, action="store_true", default=False, help=argparse.SUPPRESS)
+    # superset
+    p.add_argument("--synthetic", type=int, default=0, help="run on N seeded synthetic images with synthetic weights")
+    p.add_argument("--synthetic_classes", type=int, default=4)
+    p.add_argument("--tiny", action="store_true", help="use the tiny test architecture (with --synthetic)")
+    p.add_argument("--data_root", type=str, default="data")
+    p.add_argument("--device", type=str, default=None)
+    args = p.parse_args(argv)
+    env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
+    if env_local_rank != -1:
+        args.local_rank = env_local_rank
+    if args.text_to_img:
+        raise SystemExit("--text_to_img is broken in the reference (generate_data.py:1155 uses `generator` before assignment) and is "
+                         "out of scope")
+    if not args.do_classifier_free_guidance:
+        raise SystemExit("the engine always runs classifier-free guidance (the reference's type=bool flag cannot be switched off either)")
+    return args
+
+
+# ------------------------------------------------------------------------------------------------
+# dataset side: the reference's SDDataset.__getitem__ dict (dataloader.py:813-849), from caches or synthetic
+# ------------------------------------------------------------------------------------------------
+class ExpansionDataset:
+    """image_latents [N,4,L,L], per-class text embeds [C,T,Dm], uncond embeds [1,T,Dm], targets, class names, image paths."""
+
+    def __init__(self, latents, class_embeds, uncond_embeds, targets, class_names, image_paths):
+        self.latents, self.class_embeds, self.uncond = latents, class_embeds, uncond_embeds
+        self.targets, self.class_names, self.image_paths = targets, class_names, image_paths
+
+    def __len__(self):
+        return self.latents.shape[0]
+
+    @staticmethod
+    def synthetic(cfg, n, n_classes, seed):
+        g = torch.Generator().manual_seed(seed)
+        L = cfg.latent_size
+        per = math.ceil(n / n_classes)
+        targets = torch.tensor([min(i // per, n_classes - 1) for i in range(n)])     # class-sorted like the reference datasets
+        names = ["class %d" % c for c in range(n_classes)]
+        return ExpansionDataset(torch.randn(n, 4, L, L, generator=g) * 0.9,
+                                torch.randn(n_classes, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
+                                torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
+                                targets, names, ["%s/image_%04d.jpg" % (names[int(t)], i) for i, t in enumerate(targets)])
+
+    @staticmethod
+    def from_caches(args, cfg):
+        """Caltech-101 listing as dataloader.py:272-315 + the reference's latent cache (dataloader.py:788-796)."""
+        root = os.path.join(args.data_root, "caltech-101", "101_ObjectCategories") if args.dataset == "caltech-101" else \
+            os.path.join(args.data_root, args.dataset)
+        if not os.path.isdir(root):
+            raise SystemExit("dataset directory %s not found (supported listings: caltech-101; or use --synthetic N)" % root)
+        classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)) and d not in ("BACKGROUND_Google", "Faces_easy"))
+        paths, targets = [], []
+        for ci, c in enumerate(classes):
+            for f in sorted(os.listdir(os.path.join(root, c))):
+                paths.append(os.path.join(root, c, f))
+                targets.append(ci)
+        names = [c.replace("_", " ") for c in classes]                     # dataloader.py:129
+        cache = os.path.join("save", "vae_embedding", args.dataset, args.pretrained_model_name_or_path.replace("/", "--"))
+        lat_p, txt_p = os.path.join(cache, "image_latents.pt"), os.path.join(cache, "text_embeds.pt")
+        if not (os.path.exists(lat_p) and os.path.exists(txt_p)):
+            raise SystemExit("latent/text caches %s, %s not found: the VAE encoder and CLIP text encoder are the next rows to build "
+                             "(SURVEY.md section 8f-2); produce the caches with the reference once, or use --synthetic N" % (lat_p, txt_p))
+        lat = torch.cat([x.float() for x in torch.load(lat_p, map_location="cpu")], dim=0)
+        te = torch.load(txt_p, map_location="cpu")
+        return ExpansionDataset(lat, te["class_embeds"].float(), te["uncond_embeds"].float(), torch.tensor(targets), names, paths)
+
+
+def output_path(output_dir, class_name, image_path, image_i):
+    """generate_data.py:1134-1135 / 1231-1232."""
+    stem = os.path.basename(image_path).split(".")[0]
+    return "%s/%s/%s_expand_%d.png" % (output_dir, class_name, stem, image_i)
+
+
+def save_png(img_chw_01, path):
+    """torchvision.utils.save_image semantics for a single image: mul(255).add_(0.5).clamp_(0,255) -> uint8 -> PNG."""
+    from PIL import Image
+    arr = img_chw_01.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
+    """The reference main loop, generate_data.py:1001-1009 (shard) and :1130-1236 (batches x expand index)."""
+    from .launcher import shard_range
+    from .scheduler import guide_window, start_index
+    B = args.train_batch_size
+    idx = [i for i in shard_range(len(ds), args.total_split, args.split) if i < len(ds)]
+    ts = sched.timesteps
+    n = len(ts)
+    si = start_index(args.strength, n)
+    gfirst, gcount = (0, 0)
+    if args.guidance_type:
+        gfirst, gcount = guide_window(n, args.guidance_step, args.guidance_period)
+        log.info("Guidance timesteps: %s", ", ".join(str(t) for t in ts[gfirst:gfirst + gcount]))
+    written = 0
+    dev = engine.device if engine is not None else torch.device("cpu")
+    for s0 in range(0, len(idx), B):
+        bidx = idx[s0:s0 + B]
+        for image_i in range(args.first_image_index, args.num_images_per_prompt):
+            paths = [output_path(args.output_dir, ds.class_names[int(ds.targets[i])], ds.image_paths[i], image_i) for i in bidx]
+            if all(os.path.exists(p) for p in paths):                      # resume rule, :1132-1143
+                for p in paths:
+                    print("File %s exists, so skipped." % p)
+                continue
+            nb = len(bidx)
+            pad = bidx + [bidx[-1]] * (B - nb)                              # last ragged batch: pad to the static batch
+            lat = ds.latents[pad]
+            tg = ds.targets[pad]
+            noise = torch.randn(lat.shape, generator=None, device=rng_device).to(lat.dtype)      # :1170 (global RNG)
+            e = torch.rand([B, 4, 1, 1])                                    # :692 CPU global RNG
+            b = torch.zeros([B, 4, 1, 1]).normal_(0, 1)                     # :694
+            emb = torch.cat([ds.uncond.expand(B, -1, -1), ds.class_embeds[tg]])   # cat[negative, prompt], :1184
+            engine.set_prompt(emb.to(dev))
+            z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
+            if args.guidance_type:
+                log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, float(score))
+            for k in range(nb):
+                writer(img[k], paths[k])
+                written += 1
+    return written
+
+
+def build_engine(args):
+    from .config import from_model_dir, sd15_config, tiny_config
+    from .engine import Engine
+    from .model_utils import create_model
+    from .scheduler import DDIMSchedule
+    from .weights import load_guide_checkpoint, load_safetensors_dir, synthetic_weights
+    B = args.train_batch_size
+    latent = args.resolution // 8
+    if args.synthetic:
+        cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
+        weights = synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes)
+    else:
+        path = args.pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            raise SystemExit("%s is not a local model directory (no network access here); pass a local Hugging Face layout with unet/ and "
+                             "vae/ safetensors, or use --synthetic N" % path)
+        cfg = from_model_dir(path, latent, B)
+        vae_sd = {k: v for k, v in load_safetensors_dir(path, "vae").items() if k.startswith(("decoder.", "post_quant_conv."))}
+        guide = create_model(args.arch, pretrained=False, num_classes=1, weight_path=args.encoder_weight_path)
+        weights = {"unet": load_safetensors_dir(path, "unet"), "vae": vae_sd, "guide": guide.state_dict()}
+    guided = bool(args.guidance_type)
+    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=max(1, args.guidance_period), device=args.device or "cuda:0")
+    sched = DDIMSchedule(cfg.scheduler)
+    ts = sched.set_timesteps(args.steps)
+    targets = (args.optimize_targets or "").split("-")
+    eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=args.guidance_scale, gs=args.gs, ls=args.ls,
+                     rho=args.rho, constraint_value=args.constraint_value, use_global="global_prototype" in targets,
+                     use_local="local_prototype" in targets, guidance_period=args.guidance_period)
+    return cfg, eng, sched
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO)
+    if args.seed is not None:
+        import random
+        import numpy as np
+        random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)   # accelerate.set_seed, :861
+    if args.guidance_type not in (None, "transform_guidance", "direct_guidance"):
+        raise SystemExit("unknown --guidance_type %r" % args.guidance_type)
+    if args.guidance_type and args.arch != "resnet50" and not args.synthetic:
+        raise SystemExit("guide arch %r: only resnet50 is built (SURVEY.md section 8f-4)" % args.arch)
+    cfg, eng, sched = build_engine(args)
+    if args.synthetic:
+        ds = ExpansionDataset.synthetic(cfg, args.synthetic, args.synthetic_classes, seed=args.seed or 0)
+        if args.guidance_type:
+            g = torch.Generator().manual_seed(3)
+            D = cfg.guide.feature_dim
+            Pc = torch.randn(args.synthetic_classes, D, generator=g)
+            Pg = torch.randn(args.synthetic_classes, args.K, D, generator=g)
+    else:
+        ds = ExpansionDataset.from_caches(args, cfg)
+        if args.guidance_type:
+            from .prototypes import extract_prototypes_with_encoder
+            assert args.encoder_weight_path and os.path.exists(args.encoder_weight_path)       # :1108
+            Pc, Pg = extract_prototypes_with_encoder(args, eng, ds)
+    if args.guidance_type:
+        Pc = Pc / Pc.norm(dim=-1, keepdim=True)                            # re-normalisation, :1115-1116, 1121-1122
+        Pg = Pg / Pg.norm(dim=-1, keepdim=True)
+        print("optimize strategy: %s, target: %s, learning rate: %s" % (args.guidance_type, args.optimize_targets, args.rho))
+        eng.set_prototypes(Pc, Pg)
+    n = run_expansion(args, eng, sched, ds)
+    torch.cuda.synchronize()
+    log.info("wrote %d images under %s", n, args.output_dir)
+    eng.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

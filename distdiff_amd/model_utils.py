@@ -1,0 +1,81 @@
+"""Guide-model plugin surface of the reference (model_utils.py:43-104): `create_model(...)` returns an object with
+`encode_image(x[B,3,S,S]) -> [B,D]` (= forward_features -> global average pool -> flatten, model_utils.py:29-41),
+`forward(x) -> logits`, `.eval() / .float() / .to() / .cuda()`, and loads `{'state_dict': ...}` checkpoints with an optional
+`module.` prefix (model_utils.py:89-101). The arithmetic runs in the engine's ResNet-50 program (BN folded, bf16 MFMA).
+Only resnet50 is built (SURVEY.md section 8f-4 lists the other four architectures as next rows)."""
+import torch
+
+from .weights import load_guide_checkpoint, synthetic_guide
+
+SUPPORTED = ("resnet50",)
+
+
+class GuideModel:
+    def __init__(self, name, state_dict, num_classes):
+        self.name, self._sd, self.num_classes = name, state_dict, num_classes
+        self._engine = None
+
+    # torch.nn.Module-like surface the reference touches
+    def state_dict(self):
+        return self._sd
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._sd if k not in sd and not k.endswith("num_batches_tracked")]
+        if strict and missing:
+            raise RuntimeError("missing keys: %s" % missing[:5])
+        self._sd = {k: v.float() for k, v in sd.items()}
+
+    def eval(self):
+        return self          # BatchNorm always uses running statistics
+
+    def float(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def bind(self, engine):
+        """Attach to an Engine whose guide program was built from this state dict."""
+        self._engine = engine
+        return self
+
+    def encode_image(self, x, pooling="avg"):
+        if pooling != "avg":
+            raise ValueError("Unsupported pooling type. Only 'avg' is built in the HIP engine.")
+        if self._engine is None:
+            raise RuntimeError("GuideModel is not bound to an Engine (there is no CPU fallback): call .bind(engine)")
+        B = self._engine.B
+        outs = []
+        for i in range(0, x.shape[0], B):
+            xb = x[i:i + B]
+            n = xb.shape[0]
+            if n < B:
+                xb = torch.cat([xb, xb[-1:].expand(B - n, -1, -1, -1)])
+            outs.append(self._engine.guide_encode(xb)[:n].clone())
+        return torch.cat(outs)
+
+    def forward(self, x):
+        f = self.encode_image(x)
+        w, b = self._sd["fc.weight"].to(f.device), self._sd["fc.bias"].to(f.device)
+        return torch.nn.functional.linear(f, w, b)   # classifier head: not on the expansion hot path
+
+    __call__ = forward
+
+
+def create_model(model_name, num_classes=1000, pretrained=False, class_names=None, cache_dir=None, dataset_name=None,
+                 weight_path=None, cfg=None):
+    print("=> creating model '{}'".format(model_name))
+    if model_name not in SUPPORTED:
+        raise NotImplementedError("guide arch %r is not built yet (resnet50 only; SURVEY.md section 8f-4)" % model_name)
+    from .config import sd15_config
+    sd = synthetic_guide(cfg or sd15_config(), seed=0, num_classes=num_classes)   # shapes of timm resnet50 + fc(num_classes)
+    model = GuideModel(model_name, sd, num_classes)
+    if pretrained:
+        model.load_state_dict(torch.load("save/%s_imagenet1k.pth" % model_name, map_location="cpu"), strict=False)
+    if weight_path is not None and weight_path != "None":
+        model.load_state_dict(load_guide_checkpoint(weight_path), strict=True)
+        print("Load pretrained weights from : %s" % weight_path)
+    return model

@@ -1,0 +1,49 @@
+"""Hierarchical prototype builder, mirroring dataloader.py:664-747: guide features of every train image
+(224x224, ImageNet mean/std) -> L2-normalise -> class mean = global prototype; average-linkage agglomerative clustering
+into K groups per class -> group means. The features come from the HIP ResNet-50 (engine.guide_encode); the clustering
+is the reference's own sklearn call."""
+import numpy as np
+import torch
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _load_image(path, size):
+    from PIL import Image
+    im = Image.open(path).convert("RGB").resize((size, size), Image.BILINEAR)     # transforms.Resize((224,224)) default bilinear
+    x = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    m, s = torch.tensor(IMAGENET_MEAN)[:, None, None], torch.tensor(IMAGENET_STD)[:, None, None]
+    return (x - m) / s
+
+
+def prototypes_from_features(feats, targets, num_classes, K):
+    """dataloader.py:699-731 on L2-normalised features [N,D]."""
+    from sklearn.cluster import AgglomerativeClustering
+    feats = np.asarray(feats, dtype=np.float32)
+    targets = np.asarray(targets)
+    glob, loc = [], []
+    for c in range(num_classes):
+        f = feats[targets == c]
+        glob.append(f.mean(axis=0))
+        labels = AgglomerativeClustering(n_clusters=K, linkage="average").fit(f).labels_
+        loc.append(np.stack([f[labels == k].mean(axis=0) for k in range(K)]))
+    return np.array(glob), np.array(loc)
+
+
+def extract_prototypes_with_encoder(args, engine, ds, batch_size=64):
+    size = engine.cfg.guide.input_size
+    feats = []
+    B = engine.B
+    for i in range(0, len(ds), B):
+        paths = ds.image_paths[i:i + B]
+        x = torch.stack([_load_image(p, size) for p in paths])
+        n = x.shape[0]
+        if n < B:
+            x = torch.cat([x, x[-1:].expand(B - n, -1, -1, -1)])
+        f = engine.guide_encode(x.to(engine.device))[:n].float()
+        f = f / f.norm(dim=-1, keepdim=True)                                       # dataloader.py:677
+        feats.append(f.cpu())
+    feats = torch.cat(feats).numpy()
+    g, l = prototypes_from_features(feats, ds.targets.numpy(), len(ds.class_names), args.K)
+    return torch.from_numpy(g), torch.from_numpy(l)
