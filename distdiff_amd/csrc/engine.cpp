@@ -8,6 +8,7 @@
 // (288 GB HBM makes a full stash viable), the reverse program is built once at finalize time.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -127,15 +128,15 @@ struct Profiler {   // HIP-event timing of every op, by kernel family (dd_profil
   bool on = false;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  struct Rec { int fam; double flops; size_t e0; };
+  struct Rec { int fam; double flops; size_t e0; int M, N, K, bwd; };
   std::vector<Rec> recs;
   hipEvent_t get() {
     if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
     return pool[used++];
   }
-  void begin(int fam, double flops, hipStream_t s) {
+  void begin(int fam, double flops, hipStream_t s, int M = 0, int N = 0, int K = 0, int bwd = 0) {
     if (!on) return;
-    Rec r; r.fam = fam; r.flops = flops; r.e0 = used;
+    Rec r; r.fam = fam; r.flops = flops; r.e0 = used; r.M = M; r.N = N; r.K = K; r.bwd = bwd;
     hipEventRecord(get(), s); get();
     recs.push_back(r);
   }
@@ -452,7 +453,11 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
     const Op& op = P.ops[i];
     const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
                     : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
-    if (c.prof) c.prof->begin(fam, (op.kind == OP_CONV || op.kind == OP_ATTN) ? op.flops : 0.0, c.s);
+    if (c.prof) {
+      if (op.kind == OP_CONV) c.prof->begin(fam, op.flops, c.s, P.t[op.y].rows, op.cw->sf.N, op.cw->sf.K, 0);
+      else if (op.kind == OP_ATTN) c.prof->begin(fam, op.flops, c.s, op.Nq, op.Nk, op.D, 0);
+      else c.prof->begin(fam, 0.0, c.s, P.t[op.x].rows, P.t[op.x].C, 0, 0);
+    }
     switch (op.kind) {
       case OP_CONV: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
@@ -526,7 +531,11 @@ void run_bwd(const Program& P, const Ctx& c) {
     const Op& op = P.ops[i];
     const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
                     : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
-    if (c.prof) c.prof->begin(fam, op.kind == OP_CONV ? op.flops : op.kind == OP_ATTN ? op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5) : 0.0, c.s);
+    if (c.prof) {
+      if (op.kind == OP_CONV) c.prof->begin(fam, op.flops, c.s, P.t[op.x].rows << (2 * op.up), op.cw->sb.N, op.cw->sb.K, 1);
+      else if (op.kind == OP_ATTN) c.prof->begin(fam, op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5), c.s, op.Nq, op.Nk, op.D, 1);
+      else c.prof->begin(fam, 0.0, c.s, P.t[op.x].rows, P.t[op.x].C, 0, 1);
+    }
     struct EndGuard { const Ctx& c; ~EndGuard() { if (c.prof) c.prof->end(c.s); } } _guard{c};
     switch (op.kind) {
       case OP_CONV: {
@@ -1327,13 +1336,45 @@ int dd_profile_read(dd_engine* E, double* out12) {
   DD_TRY(E, {
     HIPCHK(hipDeviceSynchronize());
     for (int i = 0; i < 12; ++i) out12[i] = 0;
+    FILE* dump = getenv("DD_PROFILE_DUMP") ? fopen(getenv("DD_PROFILE_DUMP"), "w") : nullptr;
+    if (dump) fprintf(dump, "fam,bwd,M,N,K,flops,ms\n");
     for (auto& r : E->prof.recs) {
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, E->prof.pool[r.e0], E->prof.pool[r.e0 + 1]));
+      if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%.5f\n", r.fam, r.bwd, r.M, r.N, r.K, r.flops, ms);
       out12[r.fam * 3 + 0] += ms; out12[r.fam * 3 + 1] += r.flops; out12[r.fam * 3 + 2] += 1;
     }
+    if (dump) fclose(dump);
     E->prof.used = 0; E->prof.recs.clear();
   });
+}
+
+// ---- debug introspection: copy activation / gradient of tensor `idx` of program `prog` (0 unet, 1 vae, 2 guide), instance 0,
+// to a HOST fp32 buffer [rows*ld]; info4 = {rows, C, ld, is_f32}. Synchronises.
+int dd_debug_tensor(dd_engine* E, int prog, int idx, int want_grad, float* host_out, int* info4) {
+  if (!E || prog < 0 || prog > 2) return DD_ERR_ARG;
+  DD_TRY(E, {
+    Program& P = prog == 0 ? E->unet : prog == 1 ? E->vae : E->guide;
+    if (idx < 0 || idx >= (int)P.t.size()) throw std::runtime_error("tensor index out of range");
+    const Tn& t = P.t[idx];
+    if (info4) { info4[0] = t.rows; info4[1] = t.C; info4[2] = t.ld; info4[3] = t.f32 ? 1 : 0; }
+    if (!host_out) return DD_OK;
+    HIPCHK(hipDeviceSynchronize());
+    char* base = want_grad ? E->grad_slab + t.goff : (prog == 0 ? E->inst[0].unet : prog == 1 ? E->inst[0].vae : E->inst[0].guide) + t.off;
+    const size_t n = (size_t)t.rows * t.ld;
+    if (t.f32 && !want_grad) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
+    else {
+      std::vector<bf16_t> tmp(n);
+      // views share rows with their parent: copy row by row
+      HIPCHK(hipMemcpy2D(tmp.data(), (size_t)t.ld * 2, base, (size_t)t.ld * 2, (size_t)t.ld * 2, 1, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(tmp.data(), base, n * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) host_out[i] = host_bf2f(tmp[i]);
+    }
+  });
+}
+int dd_debug_num_tensors(dd_engine* E, int prog) {
+  if (!E || prog < 0 || prog > 2) return DD_ERR_ARG;
+  return (int)(prog == 0 ? E->unet : prog == 1 ? E->vae : E->guide).t.size();
 }
 
 size_t dd_workspace_bytes(dd_engine* e) { return e ? e->total_bytes : 0; }

@@ -69,6 +69,8 @@ def _declare(l):
     l.dd_guide_vjp.argtypes = [vp, vp, vp, vp, i, vp]
     l.dd_profile_enable.argtypes = [vp, i]
     l.dd_profile_read.argtypes = [vp, vp]
+    l.dd_debug_tensor.argtypes = [vp, i, i, i, vp, vp]
+    l.dd_debug_num_tensors.argtypes = [vp, i]
     l.dd_workspace_bytes.argtypes = [vp]
     l.dd_workspace_bytes.restype = C.c_size_t
     l.dd_flops_last.argtypes = [vp]
@@ -279,6 +281,17 @@ class Engine:
         self._chk(self.L.dd_profile_read(self._h, out), "dd_profile_read")
         names = ["conv_gemm", "attention", "norm", "other"]
         return {n: {"ms": out[3 * k], "flops": out[3 * k + 1], "ops": int(out[3 * k + 2])} for k, n in enumerate(names)}
+
+    def debug_tensor(self, prog, idx, grad=False):
+        info = (C.c_int * 4)()
+        self._chk(self.L.dd_debug_tensor(self._h, prog, idx, int(grad), None, info), "dd_debug_tensor")
+        rows, Cc, ld, f32 = list(info)
+        out = torch.empty(rows * ld, dtype=torch.float32)
+        self._chk(self.L.dd_debug_tensor(self._h, prog, idx, int(grad), vp(out.data_ptr()), info), "dd_debug_tensor")
+        return out.reshape(rows, ld)[:, :Cc]
+
+    def debug_num_tensors(self, prog):
+        return int(self.L.dd_debug_num_tensors(self._h, prog))
 
     def workspace_bytes(self):
         return int(self.L.dd_workspace_bytes(self._h))

@@ -131,6 +131,10 @@ int dd_guide_vjp(dd_engine* e, const float* images, const float* g_feats, float*
 int dd_profile_enable(dd_engine* e, int on);
 int dd_profile_read(dd_engine* e, double* out12);
 
+/* debug introspection of the op graph (program 0 unet / 1 vae / 2 guide, instance 0): host copy of an activation or gradient */
+int dd_debug_tensor(dd_engine* e, int prog, int idx, int want_grad, float* host_out, int* info4);
+int dd_debug_num_tensors(dd_engine* e, int prog);
+
 size_t dd_workspace_bytes(dd_engine* e);
 /* algorithmic MFMA-eligible FLOPs (conv/linear/attention, 2 per MAC) enqueued since the last call */
 double dd_flops_last(dd_engine* e);
