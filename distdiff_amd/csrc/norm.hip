@@ -9,10 +9,13 @@
 namespace {
 
 constexpr int GN_THREADS = 256;
-constexpr int GN_MAX_SPLIT = 64;
+constexpr int GN_MAX_SPLIT = 256;
 
-__host__ __device__ inline int gn_split(int HW) {
-  int s = HW / 256;  // >= 256 rows per block
+// rows per partial block: ~32K elements per block so that mid-size tensors still spread over hundreds of blocks
+__host__ __device__ inline int gn_split(int HW, int C) {
+  int rows = 32768 / C;
+  if (rows < 4) rows = 4;
+  int s = (HW + rows - 1) / rows;
   if (s < 1) s = 1;
   if (s > GN_MAX_SPLIT) s = GN_MAX_SPLIT;
   return s;
@@ -45,23 +48,35 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GroupNormParams 
           mean[e] = p.stats[((size_t)b * G + g) * 2]; rstd[e] = p.stats[((size_t)b * G + g) * 2 + 1];
         }
       }
-      for (int row = row_begin + my_r; row < row_end; row += R) {
-        const size_t pix = (size_t)b * p.HW + row;
-        float xv[8];
-        unpack8(*(const uint4*)(p.x + pix * p.x_ld + vc * 8), xv);
-        if (!BWD) {
+      // 4 rows in flight per thread (memory-level parallelism); accumulation order stays fixed
+      for (int row0 = row_begin + my_r; row0 < row_end; row0 += 4 * R) {
+        uint4 xr[4], dr[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
-        } else {
-          float dv[8];
-          unpack8(*(const uint4*)(p.dy + pix * p.dy_ld + vc * 8), dv);
+        for (int u = 0; u < 4; ++u) {
+          const int row = row0 + u * R;
+          const size_t pix = (size_t)b * p.HW + (row < row_end ? row : row_begin);
+          xr[u] = *(const uint4*)(p.x + pix * p.x_ld + vc * 8);
+          if (BWD) dr[u] = *(const uint4*)(p.dy + pix * p.dy_ld + vc * 8);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float xh = (xv[e] - mean[e]) * rstd[e];
-            float d = dv[e];
-            if (p.silu) d *= dsilu_f(xh * ga[e] + be[e]);
-            d *= ga[e];
-            a0[e] += d; a1[e] += d * xh;
+        for (int u = 0; u < 4; ++u) {
+          if (row0 + u * R >= row_end) continue;
+          float xv[8];
+          unpack8(xr[u], xv);
+          if (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
+          } else {
+            float dv[8];
+            unpack8(dr[u], dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xh = (xv[e] - mean[e]) * rstd[e];
+              float d = dv[e];
+              if (p.silu) d *= dsilu_f(xh * ga[e] + be[e]);
+              d *= ga[e];
+              a0[e] += d; a1[e] += d * xh;
+            }
           }
         }
       }
@@ -88,91 +103,139 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GroupNormParams 
   }
 }
 
-// Pass 2: merge partials, build per-channel affine in LDS, apply.
+// Pass 2: one wave per (b, g) merges the S partials in a fixed tree order.
+//   fwd: Chan et al. parallel merge of (n, mean, M2) -> stats[b][g] = (mean, rstd)
+//   bwd: sums -> fin[b][g] = (s1/n, s2/n)
 template <bool BWD>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p, int S) {
-  extern __shared__ float sh[];  // fwd: a[C], sh[C] ; bwd: 4 x [C] + 2 x [G]
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(GroupNormParams p, int S, float* fin) {
+  const int lane = threadIdx.x & 63;
+  const int bg = blockIdx.x * (GN_THREADS / 64) + (threadIdx.x >> 6);
+  if (bg >= p.B * p.G) return;
+  const int b = bg / p.G, g = bg % p.G;
+  const int cpg = p.C / p.G;
+  if (!BWD) {
+    float n = 0.f, mean = 0.f, M2 = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float* in = p.scratch + (((size_t)b * S + s) * p.G + g) * 3;
+      const float nb = in[0], mb = in[1], M2b = in[2];
+      if (nb > 0.f) {
+        const float nn = n + nb, d = mb - mean;
+        mean += d * (nb / nn);
+        M2 += M2b + d * d * (n * nb / nn);
+        n = nn;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), M2b = __shfl_xor(M2, o, 64);
+      // symmetric merge (both partners compute the same result, in the same operand order)
+      const float nn = n + nb;
+      if (nn > 0.f) {
+        const float lo_n = (lane & o) ? nb : n, hi_n = (lane & o) ? n : nb;
+        const float lo_m = (lane & o) ? mb : mean, hi_m = (lane & o) ? mean : mb;
+        const float lo_M = (lane & o) ? M2b : M2, hi_M = (lane & o) ? M2 : M2b;
+        const float d = hi_m - lo_m;
+        mean = lo_m + d * (hi_n / nn);
+        M2 = lo_M + hi_M + d * d * (lo_n * hi_n / nn);
+        n = nn;
+      }
+    }
+    if (lane == 0) {
+      p.stats[((size_t)b * p.G + g) * 2] = mean;
+      p.stats[((size_t)b * p.G + g) * 2 + 1] = rsqrtf(M2 / n + p.eps);
+    }
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float* in = p.scratch + (((size_t)b * S + s) * p.G + g) * 3;
+      s1 += in[0]; s2 += in[1];
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+      const float n = (float)p.HW * cpg;
+      fin[((size_t)b * p.G + g) * 2] = s1 / n;
+      fin[((size_t)b * p.G + g) * 2 + 1] = s2 / n;
+    }
+  }
+}
+
+// Pass 3: build the per-channel affine in LDS, stream the tensor (4 vectors in flight per thread).
+template <bool BWD>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p, const float* fin) {
+  extern __shared__ float sh[];
   const int C = p.C, G = p.G, cpg = C / G, VC = C >> 3;
   const int b = blockIdx.y;
-  float* A = sh;          // fwd: scale ; bwd: rstd*gamma
+  float* A = sh;          // fwd: scale ; bwd: gamma
   float* Bv = sh + C;     // fwd: shift ; bwd: mean
   float* Cv = sh + 2 * C; // bwd: rstd
-  float* Dv = sh + 3 * C; // bwd: c1 = s1/n*rstd ... per channel
-  float* Ev = sh + 4 * C; // bwd: c2
-  for (int g = threadIdx.x; g < G; g += GN_THREADS) {
+  float* Dv = sh + 3 * C; // bwd: s1/n
+  float* Ev = sh + 4 * C; // bwd: s2/n
+  float* Fv = sh + 5 * C; // bwd: beta
+  for (int c = threadIdx.x; c < C; c += GN_THREADS) {
+    const int g = c / cpg;
+    const float mean = p.stats[((size_t)b * G + g) * 2], rstd = p.stats[((size_t)b * G + g) * 2 + 1];
     if (!BWD) {
-      // Chan et al. parallel merge of (n, mean, M2)
-      float n = 0.f, mean = 0.f, M2 = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float* in = p.scratch + (((size_t)b * S + s) * G + g) * 3;
-        const float nb = in[0], mb = in[1], M2b = in[2];
-        if (nb > 0.f) {
-          const float nn = n + nb, d = mb - mean;
-          mean += d * (nb / nn);
-          M2 += M2b + d * d * (n * nb / nn);
-          n = nn;
-        }
-      }
-      const float var = M2 / n;
-      const float rstd = rsqrtf(var + p.eps);
-      if (blockIdx.x == 0) {
-        p.stats[((size_t)b * G + g) * 2] = mean;
-        p.stats[((size_t)b * G + g) * 2 + 1] = rstd;
-      }
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const float a = rstd * p.gamma[c];
-        A[c] = a; Bv[c] = p.beta[c] - mean * a;
-      }
+      const float a = rstd * p.gamma[c];
+      A[c] = a; Bv[c] = p.beta[c] - mean * a;
     } else {
-      float s1 = 0.f, s2 = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float* in = p.scratch + (((size_t)b * S + s) * G + g) * 3;
-        s1 += in[0]; s2 += in[1];
-      }
-      const float n = (float)p.HW * cpg;
-      const float mean = p.stats[((size_t)b * G + g) * 2], rstd = p.stats[((size_t)b * G + g) * 2 + 1];
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        A[c] = p.gamma[c]; Bv[c] = mean; Cv[c] = rstd; Dv[c] = s1 / n; Ev[c] = s2 / n;
-      }
+      A[c] = p.gamma[c]; Bv[c] = mean; Cv[c] = rstd; Fv[c] = p.beta[c];
+      Dv[c] = fin[((size_t)b * G + g) * 2]; Ev[c] = fin[((size_t)b * G + g) * 2 + 1];
     }
   }
   __syncthreads();
-  const int rows_per = (p.HW + gridDim.x - 1) / gridDim.x;
-  const int row_begin = blockIdx.x * rows_per, row_end = min(p.HW, row_begin + rows_per);
-  const int total = (row_end - row_begin) * VC;
-  for (int idx = threadIdx.x; idx < total; idx += GN_THREADS) {
-    const int row = row_begin + idx / VC, vc = idx % VC;
-    const size_t pix = (size_t)b * p.HW + row;
-    float xv[8], ov[8];
-    unpack8(*(const uint4*)(p.x + pix * p.x_ld + vc * 8), xv);
-    if (!BWD) {
+  const int total = p.HW * VC;
+  const int stride = gridDim.x * GN_THREADS;
+  for (int idx0 = blockIdx.x * GN_THREADS + threadIdx.x; idx0 < total; idx0 += 4 * stride) {
+    uint4 xr[4], dr[4], orr[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = vc * 8 + e;
-        float y = xv[e] * A[c] + Bv[c];
-        ov[e] = p.silu ? silu_f(y) : y;
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * stride;
+      if (idx < total) {
+        const int row = idx / VC, vc = idx - row * VC;
+        const size_t pix = (size_t)b * p.HW + row;
+        xr[u] = *(const uint4*)(p.x + pix * p.x_ld + vc * 8);
+        if (BWD) {
+          dr[u] = *(const uint4*)(p.dy + pix * p.dy_ld + vc * 8);
+          if (p.accumulate) orr[u] = *(const uint4*)(p.dx + pix * p.dx_ld + vc * 8);
+        }
       }
-      *(uint4*)(p.y + pix * p.y_ld + vc * 8) = pack8(ov);
-    } else {
-      float dv[8];
-      unpack8(*(const uint4*)(p.dy + pix * p.dy_ld + vc * 8), dv);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = vc * 8 + e;
-        const float xh = (xv[e] - Bv[c]) * Cv[c];
-        float d = dv[e];
-        if (p.silu) d *= dsilu_f(xh * A[c] + p.beta[c]);
-        d *= A[c];
-        ov[e] = Cv[c] * (d - Dv[c] - xh * Ev[c]);
-      }
-      bf16_t* dst = p.dx + pix * p.dx_ld + vc * 8;
-      if (p.accumulate) {
-        float old[8];
-        unpack8(*(const uint4*)dst, old);
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * stride;
+      if (idx >= total) continue;
+      const int row = idx / VC, vc = idx - row * VC;
+      const size_t pix = (size_t)b * p.HW + row;
+      float xv[8], ov[8];
+      unpack8(xr[u], xv);
+      if (!BWD) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] += old[e];
+        for (int e = 0; e < 8; ++e) {
+          const int c = vc * 8 + e;
+          const float y = xv[e] * A[c] + Bv[c];
+          ov[e] = p.silu ? silu_f(y) : y;
+        }
+        *(uint4*)(p.y + pix * p.y_ld + vc * 8) = pack8(ov);
+      } else {
+        float dv[8];
+        unpack8(dr[u], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = vc * 8 + e;
+          const float xh = (xv[e] - Bv[c]) * Cv[c];
+          float d = dv[e];
+          if (p.silu) d *= dsilu_f(xh * A[c] + Fv[c]);
+          d *= A[c];
+          ov[e] = Cv[c] * (d - Dv[c] - xh * Ev[c]);
+        }
+        if (p.accumulate) {
+          float old[8];
+          unpack8(orr[u], old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] += old[e];
+        }
+        *(uint4*)(p.dx + pix * p.dx_ld + vc * 8) = pack8(ov);
       }
-      *(uint4*)dst = pack8(ov);
     }
   }
 }
@@ -264,7 +327,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LayerNormParams p) {
 
 }  // namespace
 
-size_t groupnorm_scratch_bytes(int B, int G) { return (size_t)B * GN_MAX_SPLIT * G * 3 * sizeof(float); }
+size_t groupnorm_scratch_bytes(int B, int G) { return ((size_t)B * GN_MAX_SPLIT * G * 3 + (size_t)B * G * 2) * sizeof(float); }
 
 static size_t gn_partial_lds(int C) {
   const int VC = C / 8, VCt = VC < GN_THREADS ? VC : GN_THREADS, R = GN_THREADS / VCt;
@@ -274,27 +337,33 @@ static hipError_t gn_check(const GroupNormParams& p) {
   if (p.C % 8 || p.C % p.G || (p.x_ld & 7)) return hipErrorInvalidValue;
   return hipSuccess;
 }
+static int gn_apply_blocks(const GroupNormParams& p) {
+  int blocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
+  if (blocks < 1) blocks = 1;
+  const int cap = 2048 / (p.B > 0 ? p.B : 1) + 1;
+  if (blocks > cap) blocks = cap;
+  return blocks;
+}
+
+template <bool BWD>
+static hipError_t gn_launch(const GroupNormParams& p, hipStream_t stream) {
+  const int S = gn_split(p.HW, p.C);
+  float* fin = p.scratch + (size_t)p.B * GN_MAX_SPLIT * p.G * 3;   // [B][G][2] finalize output of the backward sums
+  hipLaunchKernelGGL((gn_partial_kernel<BWD>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
+  hipLaunchKernelGGL((gn_finalize_kernel<BWD>), dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p, S, fin);
+  hipLaunchKernelGGL((gn_apply_kernel<BWD>), dim3(gn_apply_blocks(p), p.B), dim3(GN_THREADS), (BWD ? 6 : 2) * p.C * sizeof(float), stream, p,
+                     (const float*)fin);
+  return hipGetLastError();
+}
 
 hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream) {
   if (gn_check(p) != hipSuccess || (p.y_ld & 7)) return hipErrorInvalidValue;
-  const int S = gn_split(p.HW);
-  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
-  int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
-  if (ablocks < 1) ablocks = 1;
-  if (ablocks > 512) ablocks = 512;
-  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(ablocks, p.B), dim3(GN_THREADS), 2 * p.C * sizeof(float), stream, p, S);
-  return hipGetLastError();
+  return gn_launch<false>(p, stream);
 }
 
 hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream) {
   if (gn_check(p) != hipSuccess || (p.dy_ld & 7) || (p.dx_ld & 7)) return hipErrorInvalidValue;
-  const int S = gn_split(p.HW);
-  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
-  int ablocks = (p.HW * (p.C / 8) + GN_THREADS * 8 - 1) / (GN_THREADS * 8);
-  if (ablocks < 1) ablocks = 1;
-  if (ablocks > 512) ablocks = 512;
-  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(ablocks, p.B), dim3(GN_THREADS), 5 * p.C * sizeof(float), stream, p, S);
-  return hipGetLastError();
+  return gn_launch<true>(p, stream);
 }
 
 hipError_t launch_layernorm_fwd(const LayerNormParams& p, hipStream_t stream) {
