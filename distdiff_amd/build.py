@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libdistdiff_hip.so")
-SOURCES = ["conv_gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "weights.cpp", "ops_abi.cpp", "engine.cpp"]
+SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "norm.hip", "attention.hip", "elementwise.hip", "weights.cpp", "ops_abi.cpp", "engine.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
          "-I", os.path.join(HERE, "..", "include")]
 

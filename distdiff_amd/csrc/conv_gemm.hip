@@ -14,94 +14,9 @@
 // output channels of one pixel: epilogue loads/stores are 8-byte (bf16x4) / 16-byte (fp32x4) vectors.
 #include "common.h"
 #include "kernels.h"
+#include "conv_epilogue.h"
 
 namespace {
-
-struct Epi {
-  // applies bias / GEGLU / residual / relu / mask and stores 4 consecutive output columns of row m.
-  static __device__ __forceinline__ void apply(const ConvGemmParams& p, const float* bias, int m, int nb, float* h,
-                                               float* g, int nb_gate) {
-    const int flags = p.flags;
-    int ncols;  // logical output columns
-    int ob;     // output column base
-    if (flags & CF_GEGLU) {
-      ncols = p.N >> 1;
-      ob = (nb >> 5) * 16 + (nb & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float hv = h[r] * p.alpha, gv = g[r] * p.alpha;
-        if (flags & CF_BIAS) {
-          if (nb + r < p.N) hv += bias[nb + r];
-          if (nb_gate + r < p.N) gv += bias[nb_gate + r];
-        }
-        if ((flags & CF_GEGLU_RAW) && nb + r < p.N) {
-          p.raw[(size_t)m * p.raw_ld + nb + r] = f2bf(hv);
-          p.raw[(size_t)m * p.raw_ld + nb_gate + r] = f2bf(gv);
-        }
-        h[r] = hv * gelu_f(gv);
-      }
-    } else {
-      ncols = p.N;
-      ob = nb;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = h[r] * p.alpha;
-        if ((flags & CF_BIAS) && nb + r < p.N) v += bias[nb + r];
-        h[r] = v;
-      }
-    }
-    const bool full = (ob + 4 <= ncols);
-    if (flags & CF_RES) {
-      if (flags & CF_RES_F32) {
-        const float* rp = (const float*)p.res + (size_t)m * p.res_ld + ob;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ob + r < ncols) h[r] += rp[r];
-      } else {
-        const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld + ob;
-        if (full && !(p.res_ld & 3)) {
-          uint2 rv = *(const uint2*)rp;
-          h[0] += __uint_as_float(rv.x << 16); h[1] += __uint_as_float(rv.x & 0xffff0000u);
-          h[2] += __uint_as_float(rv.y << 16); h[3] += __uint_as_float(rv.y & 0xffff0000u);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (ob + r < ncols) h[r] += bf2f(rp[r]);
-        }
-      }
-    }
-    if (flags & CF_RELU) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
-    }
-    if (flags & CF_MASK) {
-      const bf16_t* mp = p.mask + (size_t)m * p.mask_ld + ob;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (ob + r < ncols && !(bf2f(mp[r]) > 0.f)) h[r] = 0.f;
-    }
-    if (flags & CF_OUT_F32) {
-      float* yp = (float*)p.y + (size_t)m * p.y_ld + ob;
-      if (full && !(p.y_ld & 3)) {
-        *(float4*)yp = make_float4(h[0], h[1], h[2], h[3]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ob + r < ncols) yp[r] = h[r];
-      }
-    } else {
-      bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld + ob;
-      if (full && !(p.y_ld & 3)) {
-        uint2 o; o.x = pack2bf(h[0], h[1]); o.y = pack2bf(h[2], h[3]);
-        *(uint2*)yp = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ob + r < ncols) yp[r] = f2bf(h[r]);
-      }
-    }
-  }
-};
 
 template <int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvGemmParams p) {
@@ -348,8 +263,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvGemmParams p) {
 
 }  // namespace
 
-int conv_gemm_pick_split(int M, int N, int K) {
-  // Fill the 256 CUs: tiles are 128x128 (or 256x64); split K when the grid is small and K is deep.
+int conv_gemm_big_config(int M, int N, int K, int flags);
+void conv_gemm_big_tile(int cfg, int* bm, int* bn);
+hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream);
+
+static int small_split(int M, int N, int K) {
+  // 128x128 (or 256x64) tiles: split K when the grid is small and K is deep
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int ksteps = K / 64;
   if (tiles >= 192 || ksteps < 8) return 1;
@@ -359,15 +278,57 @@ int conv_gemm_pick_split(int M, int N, int K) {
   if (s < 1) s = 1;
   return s;
 }
+static int big_split(int cfg, int M, int N, int K) {
+  int bm, bn;
+  conv_gemm_big_tile(cfg, &bm, &bn);
+  const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const int ksteps = K / 64;
+  if (tiles >= 200) return 1;
+  int s = (256 + tiles - 1) / tiles;
+  if (s > ksteps / 8) s = ksteps / 8;
+  if (s > 32) s = 32;
+  if (s < 1) s = 1;
+  return s;
+}
+static int nonempty_split(int split, int ksteps) {
+  if (split < 1) split = 1;
+  if (split > ksteps) split = ksteps;
+  const int per = (ksteps + split - 1) / split;
+  return (ksteps + per - 1) / per;
+}
+
+int conv_gemm_pick_split(int M, int N, int K) {
+  int s = small_split(M, N, K);
+  for (int flags = 0; flags <= CF_GEGLU; flags += CF_GEGLU) {
+    const int cfg = conv_gemm_big_config(M, N, K, flags);
+    if (cfg) { const int b = big_split(cfg, M, N, K); if (b > s) s = b; }
+  }
+  return s;
+}
 
 hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
   if (p.K & 63) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  int split = p.ksplit > 0 ? p.ksplit : conv_gemm_pick_split(p.M, p.N, p.K);
+  const int ksteps = p.K / 64;
+  const int cfg = (p.force_small ? 0 : conv_gemm_big_config(p.M, p.N, p.K, p.flags));
+  int split = p.ksplit > 0 ? p.ksplit : (cfg ? big_split(cfg, p.M, p.N, p.K) : small_split(p.M, p.N, p.K));
   while (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > partial_cap_bytes) --split;
   if (!p.partial) split = 1;
-  p.ksplit = split;
-  // tile shape: 128x128 (2x2 waves) unless N is an odd multiple of 64 (e.g. 320) -> 256x64 (4x1 waves)
+  p.ksplit = nonempty_split(split, ksteps);
+  split = p.ksplit;
+  if (cfg) {
+    hipError_t e = launch_conv_gemm_big(p, cfg, stream);
+    if (e != hipSuccess) return e;
+    if (split > 1) {
+      const int ncols = (p.flags & CF_GEGLU) ? p.N / 2 : p.N;
+      const size_t total = (size_t)p.M * ((ncols + 3) / 4);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+      e = hipGetLastError();
+    }
+    return e;
+  }
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)conv_gemm_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 64) * 128);

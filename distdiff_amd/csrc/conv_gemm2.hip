@@ -1,0 +1,298 @@
+// K1/K2 (large shapes) — persistent big-tile implicit-GEMM convolution / linear on bf16 MFMA, gfx950.
+//
+// Same math, operand layout, LDS swizzle and epilogue as conv_gemm.hip, restructured for the shapes that
+// dominate the UNet / VAE time:
+//   * 8 waves (512 threads), tile BM x BN in {128x256, 128x320, 256x128} (a 256x256 tile spills: 128 accumulator + ~140 staging/fragment VGPRs): 1.3-2x the arithmetic intensity of the
+//     128x128 tile, so the per-XCD L2 no longer bounds the MFMA rate (MI355X: ~56 B/clk/CU of L2 vs 4 kFLOP/clk/CU);
+//     BN = 320 removes the N-padding waste of the SD-1.x channel counts (320/640/960/1280/1920/...).
+//   * persistent: each workgroup walks a list of (tile, K-split) work items and keeps the register-staged
+//     double-buffered pipeline running ACROSS items, so the first global-load latency and the epilogue of an item
+//     overlap the next item's loads: this is what fixes the shallow-K layers (K = 320: 5 K-steps per tile).
+//   * work items are dealt to XCDs in contiguous chunks (blocks b, b+8, ... share an L2) with n-tiles fastest.
+#include "common.h"
+#include "kernels.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int RPT = 64;       // tile rows per staging pass: 512 threads x 16 B = 64 rows of 128 B
+  constexpr int AV = BM / RPT, BV = BN / RPT;
+  static_assert(WM * WN == 8 && BM % RPT == 0 && BN % RPT == 0, "bad tile");
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int j = tid & 7, r0 = tid >> 3;
+
+  // ---- work list of this workgroup
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int ksteps = p.K >> 6;
+  const int per = (ksteps + p.ksplit - 1) / p.ksplit;      // host guarantees every split is non-empty
+  const int W = ntm * ntn * p.ksplit;
+  const int Gx = gridDim.x >> 3;
+  int w_first, w_end;
+  {
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int q = W >> 3, r = W & 7;
+    const int start = xcd * q + min(xcd, r);
+    w_first = start + jb;
+    w_end = start + q + (xcd < r ? 1 : 0);
+  }
+  if (w_first >= w_end) return;
+
+  const int cin = p.cin, cin8 = p.cin >> 3;
+  const bool uniform_tap = (cin & 63) == 0;
+  const int shift = p.shift, parity = p.parity;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- loader iterator (runs one K-step ahead of the compute iterator)
+  int lw = w_first, l_kt = 0, l_kend = 0, l_n0 = 0;
+  int pixb[AV], iy0[AV], ix0[AV];
+  auto setup_loader = [&](int w) {
+    const int kz = w % p.ksplit, tile = w / p.ksplit;
+    const int m0 = (tile / ntn) * BM;
+    l_n0 = (tile % ntn) * BN;
+    l_kt = kz * per;
+    l_kend = min(ksteps, l_kt + per);
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int m = m0 + r0 + RPT * i;
+      if (m < p.M) {
+        const int b = m / HoWo;
+        const int rem = m - b * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        pixb[i] = b * p.H * p.W;
+        iy0[i] = oy * p.stride;
+        ix0[i] = ox * p.stride;
+      } else {
+        pixb[i] = 0; iy0[i] = -1000000; ix0[i] = 0;
+      }
+    }
+  };
+  uint4 ra[AV], rb[BV];
+  unsigned okmask = 0;
+  auto load_step = [&]() {   // loads K-step l_kt of the loader's item into registers
+    okmask = 0;
+    const int kt = l_kt;
+    int e, coff;
+    bool ev;
+    if (uniform_tap) {
+      const int tap = (kt * 64) / cin;
+      coff = kt * 64 - tap * cin + j * 8;
+      e = p.taptab[tap];
+      ev = true;
+    } else {
+      const int k8 = kt * 8 + j;
+      const int tap = k8 / cin8;
+      ev = tap < p.ntaps;
+      coff = (k8 - tap * cin8) * 8;
+      e = p.taptab[ev ? tap : 0];
+    }
+    const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int ly = iy0[i] + dy, lx = ix0[i] + dx;
+      const int sy = ly >> shift, sx = lx >> shift;
+      bool ok = ev && ly >= 0 && lx >= 0 && sy < p.H && sx < p.W;
+      if (parity) ok = ok && (((ly | lx) & 1) == 0);
+      const unsigned off = ok ? (unsigned)(pixb[i] + sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)coff : 0u;
+      ra[i] = *(const uint4*)(p.x + off);
+      okmask |= ok ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = l_n0 + r0 + RPT * i;
+      const bool okn = n < p.N;
+      rb[i] = *(const uint4*)(p.w + (size_t)(okn ? n : 0) * p.K + (size_t)kt * 64 + j * 8);
+      okmask |= okn ? (1u << (16 + i)) : 0u;
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* A = smem + buf * BUF_BYTES;
+    unsigned char* Bt = A + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int row = r0 + RPT * i;
+      const bool ok = (okmask >> i) & 1u;
+      uint4 v = ra[i];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+      *(uint4*)(A + row * 128 + ((j ^ (row & 7)) << 4)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int row = r0 + RPT * i;
+      const bool ok = (okmask >> (16 + i)) & 1u;
+      uint4 v = rb[i];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+      *(uint4*)(Bt + row * 128 + ((j ^ (row & 7)) << 4)) = v;
+    }
+  };
+  // advance the loader to the next K-step; returns false when the work list is exhausted
+  auto advance_loader = [&]() -> bool {
+    if (++l_kt < l_kend) return true;
+    lw += Gx;
+    if (lw >= w_end) return false;
+    setup_loader(lw);
+    return true;
+  };
+
+  f32x4 acc[TN][TM];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* A = smem + buf * BUF_BYTES;
+    const unsigned char* Bt = A + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = fq + 4 * ks;
+      bf16x8 wf[TN];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int row = wn * (TN * 16) + jn * 16 + fr;
+        wf[jn] = *(const bf16x8*)(Bt + row * 128 + ((slot ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 16) + i * 16 + fr;
+        const bf16x8 xf = *(const bf16x8*)(A + row * 128 + ((slot ^ (row & 7)) << 4));
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf, acc[jn][i], 0, 0, 0);
+      }
+    }
+  };
+  const float* bias = p.bias;
+  if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  auto epilogue = [&](int w) {
+    const int kz = w % p.ksplit, tile = w / p.ksplit;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    if (p.ksplit > 1) {
+      float* part = p.partial + (size_t)kz * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int nb = n0 + wn * (TN * 16) + jn * 16 + fq * 4;
+          float* pp = part + (size_t)m * p.N + nb;
+          if (nb + 4 <= p.N && !(p.N & 3)) {
+            *(float4*)pp = make_float4(acc[jn][i][0], acc[jn][i][1], acc[jn][i][2], acc[jn][i][3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (nb + r < p.N) pp[r] = acc[jn][i][r];
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+      if (m >= p.M) continue;
+      if (p.flags & CF_GEGLU) {
+        if constexpr ((TN & 1) == 0) {
+#pragma unroll
+          for (int t = 0; t < TN / 2; ++t) {
+            const int nb = n0 + wn * (TN * 16) + (2 * t) * 16 + fq * 4;
+            if (nb >= p.N) continue;
+            float h[4], g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h[r] = acc[2 * t][i][r]; g[r] = acc[2 * t + 1][i][r]; }
+            Epi::apply(p, bias, m, nb, h, g, nb + 16);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int nb = n0 + wn * (TN * 16) + jn * 16 + fq * 4;
+          if (nb >= p.N) continue;
+          float h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = acc[jn][i][r];
+          Epi::apply(p, bias, m, nb, h, h, 0);
+        }
+      }
+    }
+  };
+
+  // ---- pipeline: loader one K-step ahead of the compute iterator, across work items
+  setup_loader(lw);
+  load_step();
+  store_step(0);
+  bool more = advance_loader();
+  __syncthreads();
+  int cw = w_first;                                   // compute iterator
+  int c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
+  zero_acc();
+  int cur = 0;
+  while (true) {
+    if (more) load_step();
+    compute(cur);
+    bool done = false;
+    if (--c_left == 0) {
+      epilogue(cw);
+      cw += Gx;
+      if (cw >= w_end) done = true;
+      else {
+        c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
+        zero_acc();
+      }
+    }
+    if (done) break;
+    if (more) { store_step(cur ^ 1); more = advance_loader(); }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int W = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit;
+  int G = W < 256 ? (W + 7) / 8 * 8 : 256;
+  hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN>), dim3(G), dim3(512), lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// tile choice for the big kernel: 0 = not applicable (use the 128x128 kernel), else config id
+int conv_gemm_big_config(int M, int N, int K, int flags) {
+  if (M < 1024 || N < 64 || K < 128) return 0;
+  const bool geglu = (flags & CF_GEGLU) != 0;
+  if (N <= 128) return 3;                          // 256 x 128
+  if (!geglu && N % 320 == 0 && (N % 256 != 0 || N == 1280)) return 2;   // 128 x 320
+  if (N % 256 == 0 || N >= 1024) return 1;         // 128 x 256
+  if (!geglu && N % 320 == 0) return 2;
+  return 0;
+}
+
+void conv_gemm_big_tile(int cfg, int* bm, int* bn) {
+  *bm = cfg == 3 ? 256 : 128;
+  *bn = cfg == 1 ? 256 : cfg == 2 ? 320 : 128;
+}
+
+hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream) {
+  switch (cfg) {
+    case 1: return run_big<2, 4, 4, 4>(p, stream);
+    case 2: return run_big<2, 4, 4, 5>(p, stream);
+    case 3: return run_big<4, 2, 4, 4>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}

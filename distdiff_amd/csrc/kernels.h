@@ -46,6 +46,7 @@ struct ConvGemmParams {
   int ksplit;
   int flags;
   float alpha;
+  int force_small;      // diagnostics: 1 forces the 128x128-tile kernel
 };
 
 // Chooses tile configuration / split-K from the shape. `partial_cap_bytes` bounds split-K workspace.

@@ -51,7 +51,7 @@ class PackedConv:
 
 
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
-              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None):
+              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False):
     """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)]."""
     p = ConvGemmParams()
     M = B * Ho * Wo
@@ -91,6 +91,7 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
     p.B, p.H, p.W, p.Ho, p.Wo, p.stride, p.shift, p.parity = B, H, W, Ho, Wo, stride, shift, parity
     p.cin, p.ntaps, p.M, p.N, p.K = pk.cin, pk.ntaps, M, pk.N, pk.K
     p.ksplit, p.flags, p.alpha = ksplit, flags, alpha
+    p.force_small = int(force_small)
     check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
     return y
 

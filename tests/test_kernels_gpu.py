@@ -49,6 +49,14 @@ CONV_CASES = [
     ("7x7_stem", 1, 3, 64, 32, 32, 7, 2, 3, 0),
     ("3x3_cout3", 1, 128, 3, 16, 16, 3, 1, 1, 0),
     ("3x3_deepK_splitk", 2, 1280, 128, 8, 8, 3, 1, 1, 0),
+    # shapes routed to the persistent big-tile kernel (M >= 1024): 128x256, 128x320, 256x128 tiles, ragged M, split-K
+    ("big_128x256", 2, 128, 256, 32, 32, 3, 1, 1, 0),
+    ("big_128x320_ragged", 2, 320, 320, 24, 25, 3, 1, 1, 0),
+    ("big_256x128", 1, 64, 128, 40, 40, 3, 1, 1, 0),
+    ("big_up2", 2, 64, 256, 16, 16, 3, 1, 1, 1),
+    ("big_stride2", 2, 64, 256, 64, 64, 3, 2, 1, 0),
+    ("big_1x1_shallowK", 2, 320, 640, 32, 32, 1, 1, 0, 0),
+    ("big_deepK_splitk", 2, 1280, 320, 24, 24, 3, 1, 1, 0),
 ]
 
 
@@ -122,10 +130,10 @@ def test_linear_epilogues(ops):
     assert float(big[:, :64].float().abs().max()) == 0.0
 
 
-def test_geglu_forward_backward(ops):
+@pytest.mark.parametrize("M,K,Fd", [(200, 128, 256), (1500, 320, 1280)])
+def test_geglu_forward_backward(ops, M, K, Fd):
     from distdiff_amd import _lib
     g = torch.Generator().manual_seed(4)
-    M, K, Fd = 200, 128, 256
     x = bf(torch.randn(M, K, generator=g))
     w = bf(torch.randn(2 * Fd, K, generator=g) / math.sqrt(K))
     bias = torch.randn(2 * Fd, generator=g) * 0.1
