@@ -15,6 +15,7 @@ struct Epi {
     if (flags & CF_GEGLU) {
       ncols = p.N >> 1;
       ob = (nb >> 5) * 16 + (nb & 15);
+      float hvv[4], gvv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float hv = h[r] * p.alpha, gv = g[r] * p.alpha;
@@ -22,11 +23,22 @@ struct Epi {
           if (nb + r < p.N) hv += bias[nb + r];
           if (nb_gate + r < p.N) gv += bias[nb_gate + r];
         }
-        if ((flags & CF_GEGLU_RAW) && nb + r < p.N) {
-          p.raw[(size_t)m * p.raw_ld + nb + r] = f2bf(hv);
-          p.raw[(size_t)m * p.raw_ld + nb_gate + r] = f2bf(gv);
-        }
+        hvv[r] = hv; gvv[r] = gv;
         h[r] = hv * gelu_f(gv);
+      }
+      if (flags & CF_GEGLU_RAW) {   // stash of the pre-activations for the VJP: two 8-byte stores
+        bf16_t* rp = p.raw + (size_t)m * p.raw_ld;
+        if (nb_gate + 4 <= p.N && !(p.raw_ld & 3)) {
+          uint2 a, b;
+          a.x = pack2bf(hvv[0], hvv[1]); a.y = pack2bf(hvv[2], hvv[3]);
+          b.x = pack2bf(gvv[0], gvv[1]); b.y = pack2bf(gvv[2], gvv[3]);
+          *(uint2*)(rp + nb) = a;
+          *(uint2*)(rp + nb_gate) = b;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb_gate + r < p.N) { rp[nb + r] = f2bf(hvv[r]); rp[nb_gate + r] = f2bf(gvv[r]); }
+        }
       }
     } else {
       ncols = p.N;

@@ -155,6 +155,7 @@ struct Ctx {  // per-call execution context
   const std::vector<std::pair<bf16_t*, bf16_t*>>* cross_kv = nullptr;  // per cross-attention slot
   double* flops = nullptr;
   Profiler* prof = nullptr;
+  bool stash = true;     // false on plain (no-VJP) steps: skip stores that only the reverse program reads
 };
 
 inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
@@ -475,7 +476,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         if (op.out_f32) flags |= CF_OUT_F32;
         if (w->geglu) {
           flags |= CF_GEGLU;
-          if (op.raw >= 0) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
+          if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
         }
         p.flags = flags;
         HIPCHK(launch_conv_gemm(p, c.partial_cap, c.s));
@@ -828,11 +829,12 @@ void check_batch(dd_engine* E, int B) {
 }
 
 // UNet forward on instance k: z fp32 NCHW -> eps2 fp32 NHWC [2B*HW, ld] inside the slab
-void unet_fwd(dd_engine* E, int k, const float* z, int step_index, hipStream_t s) {
+void unet_fwd(dd_engine* E, int k, const float* z, int step_index, hipStream_t s, bool stash = true) {
   const dd_config& c = E->cfg;
   Run r{E, s, c.max_batch};
   Ctx ctx = r.ctx(E->unet, E->inst[k].unet);
   ctx.step_index = step_index;
+  ctx.stash = stash;
   const Tn& in = E->unet.t[E->unet_in];
   HIPCHK(launch_nchw_f32_to_nhwc_bf16(z, act_ptr(ctx, in), c.max_batch, c.unet_in_channels, c.latent_size, c.latent_size, in.ld, in.ld, 1,
                                       1.f, s));
@@ -1137,7 +1139,7 @@ int dd_denoise_step(dd_engine* E, const float* z, int step_index, float* z_prev_
     if (step_index < 0 || step_index >= (int)E->timesteps.size()) throw std::runtime_error("step_index out of range");
     const dd_config& c = E->cfg;
     hipStream_t s = (hipStream_t)stream;
-    unet_fwd(E, 0, z, step_index, s);
+    unet_fwd(E, 0, z, step_index, s, /*stash=*/false);
     const Tn& out = E->unet.t[E->unet_out];
     HIPCHK(launch_cfg_ddim((const float*)(E->inst[0].unet + out.off), out.ld, z, z_prev_out, x0_out, B, c.unet_out_channels,
                            c.latent_size * c.latent_size, E->coef_table + (size_t)step_index * 8, s));
