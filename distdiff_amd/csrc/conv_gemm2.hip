@@ -5,7 +5,7 @@
 //   * 8 waves (512 threads), tile BM x BN in {128x256, 128x320, 256x128} (a 256x256 tile spills: 128 accumulator + ~140 staging/fragment VGPRs): 1.3-2x the arithmetic intensity of the
 //     128x128 tile, so the per-XCD L2 no longer bounds the MFMA rate (MI355X: ~56 B/clk/CU of L2 vs 4 kFLOP/clk/CU);
 //     BN = 320 removes the N-padding waste of the SD-1.x channel counts (320/640/960/1280/1920/...).
-//   * persistent: each workgroup walks a list of (tile, K-split) work items and keeps the register-staged
+//   * persistent: each workgroup walks a list of (tile, K-split) work items and keeps the LDS-DMA
 //     double-buffered pipeline running ACROSS items, so the first global-load latency and the epilogue of an item
 //     overlap the next item's loads: this is what fixes the shallow-K layers (K = 320: 5 K-steps per tile).
 //   * work items are dealt to XCDs in contiguous chunks (blocks b, b+8, ... share an L2) with n-tiles fastest.
@@ -14,6 +14,8 @@
 #include "conv_epilogue.h"
 
 namespace {
+
+__device__ uint4 g_zero16[4];   // zero page for padded taps / ragged rows (device globals are zero-initialised)
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
@@ -29,7 +31,6 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
-  const int j = tid & 7, r0 = tid >> 3;
 
   // ---- work list of this workgroup
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -52,87 +53,102 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
   const int shift = p.shift, parity = p.parity;
   const int HoWo = p.Ho * p.Wo;
 
-  // ---- loader iterator (runs one K-step ahead of the compute iterator)
-  int lw = w_first, l_kt = 0, l_kend = 0, l_n0 = 0;
-  int pixb[AV], iy0[AV], ix0[AV];
+  // ---- loader iterator (runs one K-step ahead of the compute iterator). Staging is LDS-DMA
+  // (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no zero-select): each wave-instruction fills 8 rows x 128 B
+  // linearly, so the XOR swizzle is applied on the SOURCE side: lane (row = lane>>3, physical slot = lane&7) fetches
+  // logical K-slot (lane&7) ^ (row&7). Out-of-image taps / ragged rows read a 16-byte zero page instead.
+  const int ps = lane & 7;
+  const int j = ps ^ ((lane >> 3) & 7);       // logical 16-byte K-slot this lane fetches
+  const int r0 = tid >> 3;                    // tile row of staging pass 0 (row & 7 == (lane >> 3) & 7)
+  const bool fast = uniform_tap && shift == 0 && p.ntaps <= 32;
+  int lw = w_first, l_kt = 0, l_kend = 0;
+  int pixb[AV], iy0[AV], ix0[AV];             // general path
+  unsigned tapmask[AV];                       // fast path: bit t = tap t is inside the image for this row
+  unsigned wrow[BV];                          // element offset of this lane's weight row (+ K-slot), or ~0u
   auto setup_loader = [&](int w) {
     const int kz = w % p.ksplit, tile = w / p.ksplit;
     const int m0 = (tile / ntn) * BM;
-    l_n0 = (tile % ntn) * BN;
+    const int n0 = (tile % ntn) * BN;
     l_kt = kz * per;
     l_kend = min(ksteps, l_kt + per);
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int m = m0 + r0 + RPT * i;
+      unsigned tm = 0;
+      int pb = 0, y0 = -1000000, x0 = 0;
       if (m < p.M) {
         const int b = m / HoWo;
         const int rem = m - b * HoWo;
         const int oy = rem / p.Wo;
         const int ox = rem - oy * p.Wo;
-        pixb[i] = b * p.H * p.W;
-        iy0[i] = oy * p.stride;
-        ix0[i] = ox * p.stride;
+        y0 = oy * p.stride;
+        x0 = ox * p.stride;
+        if (fast) {
+          pb = ((b * p.H + y0) * p.W + x0) * p.x_ld;     // element offset of the centre pixel
+          for (int t = 0; t < p.ntaps; ++t) {
+            const int e = p.taptab[t];
+            const int yy = y0 + ((e >> 6) & 63) - 32, xx = x0 + (e & 63) - 32;
+            tm |= (yy >= 0 && xx >= 0 && yy < p.H && xx < p.W) ? (1u << t) : 0u;
+          }
+        } else {
+          pb = b * p.H * p.W;
+        }
+      }
+      pixb[i] = pb; iy0[i] = y0; ix0[i] = x0; tapmask[i] = tm;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + r0 + RPT * i;
+      wrow[i] = n < p.N ? (unsigned)n * (unsigned)p.K + (unsigned)(j * 8) : 0xffffffffu;
+    }
+  };
+  auto issue_step = [&](int buf) {   // enqueue the LDS-DMA of K-step l_kt of the loader's item into buffer `buf`
+    const int kt = l_kt;
+    unsigned char* Abase = smem + buf * BUF_BYTES + wave * 1024;
+    unsigned char* Bbase = smem + buf * BUF_BYTES + BM * 128 + wave * 1024;
+    if (fast) {
+      const int tap = (kt * 64) / cin;                       // wave-uniform
+      const int e = p.taptab[tap];
+      const int tapoff = ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld + (kt * 64 - tap * cin) + j * 8;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const bool ok = (tapmask[i] >> tap) & 1u;
+        const bf16_t* src = ok ? p.x + (unsigned)(pixb[i] + tapoff) : (const bf16_t*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Abase + i * (RPT * 128)), 16, 0, 0);
+      }
+    } else {
+      int e, coff;
+      bool ev;
+      if (uniform_tap) {
+        const int tap = (kt * 64) / cin;
+        coff = kt * 64 - tap * cin + j * 8;
+        e = p.taptab[tap];
+        ev = true;
       } else {
-        pixb[i] = 0; iy0[i] = -1000000; ix0[i] = 0;
+        const int k8 = kt * 8 + j;
+        const int tap = k8 / cin8;
+        ev = tap < p.ntaps;
+        coff = (k8 - tap * cin8) * 8;
+        e = p.taptab[ev ? tap : 0];
+      }
+      const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int ly = iy0[i] + dy, lx = ix0[i] + dx;
+        const int sy = ly >> shift, sx = lx >> shift;
+        bool ok = ev && ly >= 0 && lx >= 0 && sy < p.H && sx < p.W;
+        if (parity) ok = ok && (((ly | lx) & 1) == 0);
+        const bf16_t* src = ok ? p.x + ((unsigned)(pixb[i] + sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)coff) : (const bf16_t*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Abase + i * (RPT * 128)), 16, 0, 0);
       }
     }
-  };
-  uint4 ra[AV], rb[BV];
-  unsigned okmask = 0;
-  auto load_step = [&]() {   // loads K-step l_kt of the loader's item into registers
-    okmask = 0;
-    const int kt = l_kt;
-    int e, coff;
-    bool ev;
-    if (uniform_tap) {
-      const int tap = (kt * 64) / cin;
-      coff = kt * 64 - tap * cin + j * 8;
-      e = p.taptab[tap];
-      ev = true;
-    } else {
-      const int k8 = kt * 8 + j;
-      const int tap = k8 / cin8;
-      ev = tap < p.ntaps;
-      coff = (k8 - tap * cin8) * 8;
-      e = p.taptab[ev ? tap : 0];
-    }
-    const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int ly = iy0[i] + dy, lx = ix0[i] + dx;
-      const int sy = ly >> shift, sx = lx >> shift;
-      bool ok = ev && ly >= 0 && lx >= 0 && sy < p.H && sx < p.W;
-      if (parity) ok = ok && (((ly | lx) & 1) == 0);
-      const unsigned off = ok ? (unsigned)(pixb[i] + sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)coff : 0u;
-      ra[i] = *(const uint4*)(p.x + off);
-      okmask |= ok ? (1u << i) : 0u;
-    }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      const int n = l_n0 + r0 + RPT * i;
-      const bool okn = n < p.N;
-      rb[i] = *(const uint4*)(p.w + (size_t)(okn ? n : 0) * p.K + (size_t)kt * 64 + j * 8);
-      okmask |= okn ? (1u << (16 + i)) : 0u;
-    }
-  };
-  auto store_step = [&](int buf) {
-    unsigned char* A = smem + buf * BUF_BYTES;
-    unsigned char* Bt = A + BM * 128;
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int row = r0 + RPT * i;
-      const bool ok = (okmask >> i) & 1u;
-      uint4 v = ra[i];
-      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-      *(uint4*)(A + row * 128 + ((j ^ (row & 7)) << 4)) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BV; ++i) {
-      const int row = r0 + RPT * i;
-      const bool ok = (okmask >> (16 + i)) & 1u;
-      uint4 v = rb[i];
-      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-      *(uint4*)(Bt + row * 128 + ((j ^ (row & 7)) << 4)) = v;
+      const bf16_t* src = wrow[i] != 0xffffffffu ? p.w + ((size_t)wrow[i] + (size_t)kt * 64) : (const bf16_t*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Bbase + i * (RPT * 128)), 16, 0, 0);
     }
   };
   // advance the loader to the next K-step; returns false when the work list is exhausted
@@ -228,10 +244,11 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
     }
   };
 
-  // ---- pipeline: loader one K-step ahead of the compute iterator, across work items
+  // ---- pipeline: loader one K-step ahead of the compute iterator, across work items.
+  // __syncthreads() carries the vmcnt(0) that retires the DMA (an LDS-DMA is a pending LDS write for the fence), so a
+  // buffer is read one barrier after its DMA was issued and re-filled one barrier after its last read.
   setup_loader(lw);
-  load_step();
-  store_step(0);
+  issue_step(0);
   bool more = advance_loader();
   __syncthreads();
   int cw = w_first;                                   // compute iterator
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
   zero_acc();
   int cur = 0;
   while (true) {
-    if (more) load_step();
+    if (more) issue_step(cur ^ 1);
     compute(cur);
     bool done = false;
     if (--c_left == 0) {
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
       }
     }
     if (done) break;
-    if (more) { store_step(cur ^ 1); more = advance_loader(); }
+    if (more) more = advance_loader();
     __syncthreads();
     cur ^= 1;
   }
