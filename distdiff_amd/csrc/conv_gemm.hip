@@ -310,7 +310,7 @@ hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStrea
   if (p.K & 63) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   const int ksteps = p.K / 64;
-  int cfg = (p.force_small ? 0 : conv_gemm_big_config(p.M, p.N, p.K, p.flags));
+  int cfg = ((p.force_small & 1) ? 0 : conv_gemm_big_config(p.M, p.N, p.K, p.flags));
   if (cfg && p.ksplit <= 0) {
     // the persistent kernel runs one 8-wave workgroup per CU: it needs >= ~3/4 of the 256 CUs busy, else the
     // 128x128 kernel (2-3 workgroups per CU, more of them) wins
