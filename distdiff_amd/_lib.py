@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdistdiff_hip.so")
+LIB_PATH = os.environ.get("DD_LIB") or os.path.join(_HERE, "libdistdiff_hip.so")   # DD_LIB: A/B builds for benchmarking
 
 _lib = None
 
