@@ -49,6 +49,31 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, int S, const bf16
     *(uint4*)(lds + r * S + v * 16) = val;
   }
 }
+// register-staged variant: issue the global loads of a tile early, write them to LDS after the compute of the previous tile
+template <int ROWS, int DPK>
+struct TileRegs { uint4 v[(ROWS * (DPK / 8) + 255) / 256]; };
+template <int ROWS, int DPK>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS, DPK>& t, const bf16_t* g, int ld, int nvalid, int D, int tid) {
+  constexpr int VPR = DPK / 8, N = (ROWS * VPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx / VPR, v = idx % VPR;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (idx < ROWS * VPR && r < nvalid && v * 8 < D) val = *(const uint4*)(g + (size_t)r * ld + v * 8);
+    t.v[i] = val;
+  }
+}
+template <int ROWS, int DPK>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS, DPK>& t, unsigned char* lds, int S, int tid) {
+  constexpr int VPR = DPK / 8, N = (ROWS * VPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx / VPR, v = idx % VPR;
+    if (idx < ROWS * VPR) *(uint4*)(lds + r * S + v * 16) = t.v[i];
+  }
+}
 template <int DPK>
 __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* g, bool valid, int D, int lane) {
   const int gq = lane >> 4;
@@ -106,11 +131,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
   const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
 
+  // K/V tiles are register-staged one tile ahead (global latency hides under the MFMAs of the current tile) for the small
+  // head dims; d = 512 keeps the direct staging (its tile would need 64 staging VGPRs)
+  constexpr bool PREFETCH = (DPK <= 160);
+  TileRegs<KT, PREFETCH ? DPK : 32> kreg, vreg;
+  if (PREFETCH) {
+    tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
+    tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg, p.ldv, p.Nk, D, tid);
+  }
   for (int k0 = 0; k0 < p.Nk; k0 += KT) {
     __syncthreads();
-    stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
-    stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    if (PREFETCH) {
+      tile_store<KT, PREFETCH ? DPK : 32>(kreg, Ks, S, tid);
+      tile_store<KT, PREFETCH ? DPK : 32>(vreg, Vs, S, tid);
+    } else {
+      stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
+      stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    }
     __syncthreads();
+    if (PREFETCH && k0 + KT < p.Nk) {
+      tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg + (size_t)(k0 + KT) * p.ldk, p.ldk, p.Nk - k0 - KT, D, tid);
+      tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg + (size_t)(k0 + KT) * p.ldv, p.ldv, p.Nk - k0 - KT, D, tid);
+    }
     f32x4 st[QT][NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -123,36 +165,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
       }
     }
+    const bool partial = k0 + KT > p.Nk;     // wave-uniform: only the last tile of a ragged key count needs masking
     bf16x8 pf[QT][NC];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float mx = -INFINITY;
+      // softmax is VALU-bound at d = 40 (one exp per score): keep it to max + fma + exp + add per element
+      if (partial) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + 4 * g + r >= p.Nk) st[qt][kt][r] = -INFINITY;
+      }
+      float mx = st[qt][0][0];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + kt * 16 + 4 * g + r;
-          const float t = key < p.Nk ? st[qt][kt][r] * sl2 : -INFINITY;
-          st[qt][kt][r] = t;
-          mx = fmaxf(mx, t);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = exp2f(mrun[qt] - mnew);
+      const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(st[qt][kt][r] - mnew);
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
           st[qt][kt][r] = e;
           ps += e;
         }
       lsum[qt] = lsum[qt] * alpha + ps;
       mrun[qt] = mnew;
+      if (__any(alpha != 1.f)) {                              // wave-uniform: skip the O rescale when no row max moved
 #pragma unroll
-      for (int dt = 0; dt < DTW; ++dt) o[qt][dt] *= alpha;
+        for (int dt = 0; dt < DTW; ++dt) o[qt][dt] *= alpha;
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) pf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
     }
