@@ -109,7 +109,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    distributed = "RANK" in os.environ            # launched by torch.distributed.run (also with --nproc-per-node 1)
+    if distributed:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -124,7 +125,7 @@ def main():
     C_cls, K = 100, 3
     t_setup = time.time()
     weights = synthetic_weights(cfg, seed=0, num_classes=C_cls) if rank == 0 else None
-    if world > 1:
+    if distributed:
         weights = broadcast_weights(weights, cfg, src=0, device=dev)   # RCCL broadcast over xGMI
     guided = a.guidance != "none"
     eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=max(1, a.guidance_period), device=str(dev))
@@ -162,7 +163,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -183,7 +184,7 @@ def main():
     barrier()
     dt = time.time() - t0
     flops = eng.flops_last()
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -224,7 +225,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
 
