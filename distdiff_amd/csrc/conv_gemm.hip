@@ -86,8 +86,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvGemmParams p
     int e, coff;
     bool ev;
     if (uniform_tap) {
-      const int tap = (kt * 64) / cin;            // wave-uniform: scalar ALU + s_load
-      coff = kt * 64 - tap * cin + j * 8;
+      const int chunk = kt / p.ntaps;             // wave-uniform: scalar ALU + s_load; K order = (64-channel chunk, tap)
+      const int tap = kt - chunk * p.ntaps;
+      coff = chunk * 64 + j * 8;
       e = p.taptab[tap];
       ev = true;
     } else {

@@ -109,9 +109,10 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
     unsigned char* Abase = smem + buf * BUF_BYTES + wave * 1024;
     unsigned char* Bbase = smem + buf * BUF_BYTES + BM * 128 + wave * 1024;
     if (fast) {
-      const int tap = (kt * 64) / cin;                       // wave-uniform
+      const int chunk = kt / p.ntaps;                        // wave-uniform; K order = (64-channel chunk, tap)
+      const int tap = kt - chunk * p.ntaps;
       const int e = p.taptab[tap];
-      const int tapoff = ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld + (kt * 64 - tap * cin) + j * 8;
+      const int tapoff = ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld + chunk * 64 + j * 8;
 #pragma unroll
       for (int i = 0; i < AV; ++i) {
         const bool ok = (tapmask[i] >> tap) & 1u;
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
       int e, coff;
       bool ev;
       if (uniform_tap) {
-        const int tap = (kt * 64) / cin;
-        coff = kt * 64 - tap * cin + j * 8;
+        const int chunk = kt / p.ntaps;
+        const int tap = kt - chunk * p.ntaps;
+        coff = chunk * 64 + j * 8;
         e = p.taptab[tap];
         ev = true;
       } else {

@@ -36,17 +36,25 @@ void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad
       const int dy = mode == 0 ? ky - pad : pad - ky, dx = mode == 0 ? kx - pad : pad - kx;
       taptab[tap] = ((dy + 32) << 6) | (dx + 32);
     }
+  // K order: (tap, channel) in general; when the channel count is a multiple of 64 the kernels walk K as
+  // (64-channel chunk, tap, channel-in-chunk), so the 9 taps of one channel chunk are consecutive K-steps and re-read the
+  // same (shifted) input rows while they are still in L2 (conv_gemm.hip / conv_gemm2.hip, uniform-tap path)
+  const int nt = KH * KW;
+  auto kidx = [&](int t, int c) -> size_t {
+    if ((s.cin & 63) == 0) return (size_t)((c >> 6) * nt + t) * 64 + (c & 63);
+    return (size_t)t * s.cin + c;
+  };
   if (mode == 0) {
     for (int n = 0; n < Cout; ++n) {
       const int on = geglu ? geglu_perm(n, F) : n;
       for (int c = 0; c < Cin; ++c)
-        for (int t = 0; t < KH * KW; ++t) wp[(size_t)n * s.K + t * s.cin + c] = host_f2bf(w[((size_t)on * Cin + c) * KH * KW + t]);
+        for (int t = 0; t < nt; ++t) wp[(size_t)n * s.K + kidx(t, c)] = host_f2bf(w[((size_t)on * Cin + c) * nt + t]);
     }
   } else {
     for (int c = 0; c < Cin; ++c)
       for (int n = 0; n < Cout; ++n) {
         const int on = geglu ? geglu_perm(n, F) : n;
-        for (int t = 0; t < KH * KW; ++t) wp[(size_t)c * s.K + t * s.cin + n] = host_f2bf(w[((size_t)on * Cin + c) * KH * KW + t]);
+        for (int t = 0; t < nt; ++t) wp[(size_t)c * s.K + kidx(t, n)] = host_f2bf(w[((size_t)on * Cin + c) * nt + t]);
       }
   }
 }
