@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="images per step per GPU (train_batch_size)")
+    ap.add_argument("--batch", type=int, default=16, help="images per step per GPU (train_batch_size)")
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny"])
     ap.add_argument("--guidance", default="transform_guidance", choices=["transform_guidance", "direct_guidance", "none"])
     ap.add_argument("--strength", type=float, default=0.5)
