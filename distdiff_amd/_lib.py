@@ -25,6 +25,9 @@ def lib():
                 "libdistdiff_hip.so not built: run `python -m distdiff_amd.build` (needs hipcc, gfx950). "
                 "There is no CPU fallback for the product path.")
         try:
+            # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's): load torch FIRST so that this library binds to
+            # the HIP runtime instance torch uses (one runtime per process; the other order leaves a runtime that sees no device)
+            import torch  # noqa: F401
             _lib = C.CDLL(LIB_PATH)
         except OSError as e:  # missing libamdhip64 etc.
             raise DistDiffLibraryError("cannot load %s: %s" % (LIB_PATH, e))
