@@ -1379,6 +1379,15 @@ int dd_debug_num_tensors(dd_engine* E, int prog) {
   return (int)(prog == 0 ? E->unet : prog == 1 ? E->vae : E->guide).t.size();
 }
 
+// output stage (generate_data.py:1227-1234): [B,3,H,W] fp32 in [0,1] -> uint8 HWC with torchvision.save_image's quantisation
+int dd_image_to_u8(dd_engine* E, const float* image, uint8_t* out_hwc, int B, void* stream) {
+  if (!E || !image || !out_hwc || B < 1) return DD_ERR_ARG;
+  DD_TRY(E, {
+    const dd_config& c = E->cfg;
+    HIPCHK(launch_to_uint8(image, out_hwc, B, c.vae_out_channels, 8 * c.latent_size, 8 * c.latent_size, (hipStream_t)stream));
+  });
+}
+
 size_t dd_workspace_bytes(dd_engine* e) { return e ? e->total_bytes : 0; }
 double dd_flops_last(dd_engine* e) { if (!e) return 0; const double f = e->flops; e->flops = 0; return f; }
 

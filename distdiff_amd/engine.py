@@ -63,6 +63,7 @@ def _declare(l):
     l.dd_decode.argtypes = [vp, vp, vp, i, i, vp]
     l.dd_expand.argtypes = [vp, C.POINTER(DDExpandArgs), vp]
     l.dd_guide_encode.argtypes = [vp, vp, vp, i, vp]
+    l.dd_image_to_u8.argtypes = [vp, vp, vp, i, vp]
     l.dd_unet_forward.argtypes = [vp, vp, i, vp, i, vp]
     l.dd_unet_vjp.argtypes = [vp, vp, i, vp, vp, i, vp]
     l.dd_decode_vjp.argtypes = [vp, vp, vp, vp, i, vp]
@@ -227,6 +228,13 @@ class Engine:
         img = torch.empty((z.shape[0], self.cfg.vae.out_channels, L8, L8), device=self.device, dtype=torch.float32)
         self._chk(self.L.dd_decode(self._h, _p(z), _p(img), int(denormalize), z.shape[0], _stream()), "dd_decode")
         return img
+
+    def image_to_u8(self, img):
+        """[B,3,H,W] fp32 in [0,1] (device) -> uint8 [B,H,W,3] (device), save_image quantisation."""
+        img = self._f(img)
+        out = torch.empty((img.shape[0], img.shape[2], img.shape[3], 3), device=self.device, dtype=torch.uint8)
+        self._chk(self.L.dd_image_to_u8(self._h, _p(img), _p(out), img.shape[0], _stream()), "dd_image_to_u8")
+        return out
 
     def guide_encode(self, images):
         x = self._f(images)

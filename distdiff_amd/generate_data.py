@@ -148,12 +148,54 @@ def output_path(output_dir, class_name, image_path, image_i):
     return "%s/%s/%s_expand_%d.png" % (output_dir, class_name, stem, image_i)
 
 
-def save_png(img_chw_01, path):
-    """torchvision.utils.save_image semantics for a single image: mul(255).add_(0.5).clamp_(0,255) -> uint8 -> PNG."""
+def save_png(img, path):
+    """Writes one image: uint8 HWC array (already quantised on the GPU) or, for the CPU tests, a CHW float tensor in [0,1]
+    with torchvision.utils.save_image semantics (mul(255).add_(0.5).clamp_(0,255) -> uint8)."""
     from PIL import Image
-    arr = img_chw_01.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+    if isinstance(img, torch.Tensor) and img.dtype != torch.uint8:
+        img = img.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8)
+    arr = img.cpu().numpy() if isinstance(img, torch.Tensor) else img
     os.makedirs(os.path.dirname(path), exist_ok=True)
     Image.fromarray(arr).save(path)
+
+
+class AsyncPNGWriter:
+    """Output stage: quantise on the GPU, copy device->pinned host asynchronously, encode PNGs on a thread
+    pool, so the next batch's kernels are enqueued while the previous batch is read back and encoded."""
+
+    def __init__(self, engine, writer=save_png, threads=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.engine, self.writer = engine, writer
+        self.pool = ThreadPoolExecutor(max_workers=threads)
+        self.pending = None
+        self.futures = []
+        self.written = 0
+
+    def submit(self, img_dev, paths):
+        u8 = self.engine.image_to_u8(img_dev)
+        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(u8, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        prev, self.pending = self.pending, (ev, host, paths, u8)
+        self._drain(prev)
+
+    def _drain(self, item):
+        if item is None:
+            return
+        ev, host, paths, _keep = item
+        ev.synchronize()
+        for k, p in enumerate(paths):
+            self.futures.append(self.pool.submit(self.writer, host[k].numpy(), p))
+            self.written += 1
+
+    def close(self):
+        self._drain(self.pending)
+        self.pending = None
+        for f in self.futures:
+            f.result()
+        self.pool.shutdown()
+        return self.written
 
 
 def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
@@ -171,6 +213,7 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
         log.info("Guidance timesteps: %s", ", ".join(str(t) for t in ts[gfirst:gfirst + gcount]))
     written = 0
     dev = engine.device if engine is not None else torch.device("cpu")
+    async_writer = AsyncPNGWriter(engine, writer) if hasattr(engine, "image_to_u8") and dev.type == "cuda" else None
     for s0 in range(0, len(idx), B):
         bidx = idx[s0:s0 + B]
         for image_i in range(args.first_image_index, args.num_images_per_prompt):
@@ -191,9 +234,14 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
             z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
             if args.guidance_type:
                 log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, float(score))
-            for k in range(nb):
-                writer(img[k], paths[k])
-                written += 1
+            if async_writer is not None:
+                async_writer.submit(img[:nb], paths)
+            else:
+                for k in range(nb):
+                    writer(img[k], paths[k])
+                    written += 1
+    if async_writer is not None:
+        written += async_writer.close()
     return written
 
 

@@ -115,6 +115,8 @@ int dd_direct_guidance(dd_engine* e, const float* z, const int* targets, int ste
                        float* score_out, float* grad_z_out, int B, void* stream);
 int dd_decode(dd_engine* e, const float* z, float* image_out, int denormalize, int B, void* stream);
 int dd_expand(dd_engine* e, const dd_expand_args* a, void* stream);
+/* output stage: image DEVICE fp32 [B,3,8L,8L] in [0,1] -> DEVICE uint8 [B,8L,8L,3] (mul 255, add 0.5, clamp, truncate: save_image, :1227-1234) */
+int dd_image_to_u8(dd_engine* e, const float* image, uint8_t* out_hwc, int B, void* stream);
 /* images: DEVICE fp32 [B,3,S,S] (S = guide_input_size) -> feats DEVICE fp32 [B, D] */
 int dd_guide_encode(dd_engine* e, const float* images, float* feats, int B, void* stream);
 /* diagnostic: raw UNet forward, eps2_out DEVICE fp32 [2B,4,L,L] (uncond half first) */
