@@ -192,3 +192,35 @@ def test_full_size_sd15_properties(hip_lib):
     v1, v2 = eng.unet_vjp(z, 30, gg), eng.unet_vjp(z, 30, -4.0 * gg)
     assert rel(v2, -4.0 * v1) < 0.03
     eng.close()
+
+
+def test_config1_sd15_shapes_256px_guidance_off_vs_oracle(hip_lib):
+    """BASELINE.json configs[0]: real SD-1.x / AutoencoderKL shapes, 256x256 (latent 32), 10-step DDIM schedule, strength 1.0,
+    energy guidance OFF — the engine against the fp32 CPU oracle on identical seeded inputs (full architecture, not the tiny one)."""
+    from distdiff_amd.config import sd15_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    B = 1
+    cfg = sd15_config(latent_size=32, max_batch=B)
+    w = synthetic_weights(cfg, seed=0, num_classes=10)
+    eng = Engine(cfg, w, enable_grad=False, max_guidance_period=1)
+    sched = DDIMSchedule(cfg.scheduler)
+    ts = sched.set_timesteps(10)
+    eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(B, 4, 32, 32, generator=g) * 0.18215 * 5
+    noise = torch.randn(B, 4, 32, 32, generator=g)
+    pe = torch.randn(B, 77, 768, generator=g)
+    ne = torch.randn(B, 77, 768, generator=g)
+    eng.set_prompt(torch.cat([ne, pe]).cuda())
+    z, img, _ = eng.expand(lat, noise, None, None, torch.zeros(B, dtype=torch.int64), 0, None, 0, 0)
+    args = O.SamplerArgs(guidance_type=None, num_inference_steps=10, strength=1.0)
+    zr, imr, _ = O.expand_one(args, cfg, O.build_models(cfg, w), lat, noise, None, None, pe, ne, torch.zeros(B, dtype=torch.int64), None, None)
+    assert rel(z, zr) < 0.05, rel(z, zr)
+    err = (img.cpu() - imr).abs()
+    psnr = 10 * torch.log10(1.0 / (err ** 2).mean()).item()
+    assert float(err.max()) < 0.2 and psnr > 28.0, (float(err.max()), psnr)
+    eng.close()
