@@ -79,6 +79,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", type=int, default=0, help="run on N seeded synthetic images with synthetic weights")
     p.add_argument("--synthetic_classes", type=int, default=4)
     p.add_argument("--tiny", action="store_true", help="use the tiny test architecture (with --synthetic)")
+    p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = max(train_batch_size, 8)); units (image, expand index) are independent")
     p.add_argument("--data_root", type=str, default="data")
     p.add_argument("--device", type=str, default=None)
     args = p.parse_args(argv)
@@ -202,7 +203,6 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     """The reference main loop, generate_data.py:1001-1009 (shard) and :1130-1236 (batches x expand index)."""
     from .launcher import shard_range
     from .scheduler import guide_window, start_index
-    B = args.train_batch_size
     idx = [i for i in shard_range(len(ds), args.total_split, args.split) if i < len(ds)]
     ts = sched.timesteps
     n = len(ts)
@@ -214,32 +214,43 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     written = 0
     dev = engine.device if engine is not None else torch.device("cpu")
     async_writer = AsyncPNGWriter(engine, writer) if hasattr(engine, "image_to_u8") and dev.type == "cuda" else None
+    # Units of work = (train image i, expand index j), enumerated in the reference's order and filtered by its resume rule
+    # (a (batch, image_i) group is skipped when all of its PNGs exist, :1132-1143). The units are independent, so they are
+    # re-packed into engine batches of EB = engine.B images (>= train_batch_size): --train_batch_size 1 of the script of record
+    # would leave an MI355X mostly idle.
+    B = args.train_batch_size
+    EB = engine.B
+    units = []
     for s0 in range(0, len(idx), B):
         bidx = idx[s0:s0 + B]
         for image_i in range(args.first_image_index, args.num_images_per_prompt):
             paths = [output_path(args.output_dir, ds.class_names[int(ds.targets[i])], ds.image_paths[i], image_i) for i in bidx]
-            if all(os.path.exists(p) for p in paths):                      # resume rule, :1132-1143
+            if all(os.path.exists(p) for p in paths):
                 for p in paths:
                     print("File %s exists, so skipped." % p)
                 continue
-            nb = len(bidx)
-            pad = bidx + [bidx[-1]] * (B - nb)                              # last ragged batch: pad to the static batch
-            lat = ds.latents[pad]
-            tg = ds.targets[pad]
-            noise = torch.randn(lat.shape, generator=None, device=rng_device).to(lat.dtype)      # :1170 (global RNG)
-            e = torch.rand([B, 4, 1, 1])                                    # :692 CPU global RNG
-            b = torch.zeros([B, 4, 1, 1]).normal_(0, 1)                     # :694
-            emb = torch.cat([ds.uncond.expand(B, -1, -1), ds.class_embeds[tg]])   # cat[negative, prompt], :1184
-            engine.set_prompt(emb.to(dev))
-            z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
-            if args.guidance_type:
-                log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, float(score))
-            if async_writer is not None:
-                async_writer.submit(img[:nb], paths)
-            else:
-                for k in range(nb):
-                    writer(img[k], paths[k])
-                    written += 1
+            units += [(i, p) for i, p in zip(bidx, paths)]
+    for u0 in range(0, len(units), EB):
+        chunk = units[u0:u0 + EB]
+        nb = len(chunk)
+        pad = [i for i, _ in chunk] + [chunk[-1][0]] * (EB - nb)            # ragged last batch: pad to the static batch
+        paths = [p for _, p in chunk]
+        lat = ds.latents[pad]
+        tg = ds.targets[pad]
+        noise = torch.randn(lat.shape, generator=None, device=rng_device).to(lat.dtype)      # :1170 (global RNG)
+        e = torch.rand([EB, 4, 1, 1])                                   # :692 CPU global RNG
+        b = torch.zeros([EB, 4, 1, 1]).normal_(0, 1)                    # :694
+        emb = torch.cat([ds.uncond.expand(EB, -1, -1), ds.class_embeds[tg]])   # cat[negative, prompt], :1184
+        engine.set_prompt(emb.to(dev))
+        z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
+        if args.guidance_type:
+            log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, float(score))
+        if async_writer is not None:
+            async_writer.submit(img[:nb], paths)
+        else:
+            for k in range(nb):
+                writer(img[k], paths[k])
+                written += 1
     if async_writer is not None:
         written += async_writer.close()
     return written
@@ -251,7 +262,7 @@ def build_engine(args):
     from .model_utils import create_model
     from .scheduler import DDIMSchedule
     from .weights import load_guide_checkpoint, load_safetensors_dir, synthetic_weights
-    B = args.train_batch_size
+    B = args.engine_batch or max(args.train_batch_size, 8)
     latent = args.resolution // 8
     if args.synthetic:
         cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)

@@ -60,7 +60,9 @@ def test_loop_shards_paths_resume_and_call_sequence(tmp_path):
     # shard 1 of 2 over 7 images: ceil(7/2)=4 -> indices 4..6 (generate_data.py:1003-1007) -> batches [4,5], [6]
     assert n == 3 * 2 and len(written) == 6
     exp = [c for c in eng.calls if c[0] == "expand"]
-    assert len(exp) == 2 * 2                               # 2 batches x 2 expand indices
+    # units in the reference order: ([4,5],0) ([4,5],1) ([6],0) ([6],1) -> six independent units packed into engine batches of 2
+    assert len(exp) == 3
+    assert [c[6] for c in exp] == [[1, 1], [1, 1], [1, 1]]
     assert all(c[2] == 25 and c[3] == "transform_guidance" and c[4] == 30 and c[5] == 2 for c in exp)
     assert exp[0][1] == (2, 4, cfg.latent_size, cfg.latent_size)
     assert sorted(os.path.basename(p) for p in written) == sorted(
@@ -76,7 +78,7 @@ def test_loop_shards_paths_resume_and_call_sequence(tmp_path):
         os.remove(p)
     eng3 = FakeEngine(2)
     G.run_expansion(args, eng3, sched, ds, writer=lambda img, p: None)
-    assert len([c for c in eng3.calls if c[0] == "expand"]) == 2
+    assert len([c for c in eng3.calls if c[0] == "expand"]) == 2      # 3 units (indices 4,5,6 x expand index 1) -> 2 engine batches
 
 
 def test_prototype_builder_known_answer():

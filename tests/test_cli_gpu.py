@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def _run(tmp_path, split, total, extra=()):
     from distdiff_amd import generate_data as G
     out = str(tmp_path / "out")
-    argv = ["--synthetic", "6", "--tiny", "--synthetic_classes", "2", "--output_dir", out, "--train_batch_size", "2", "--steps", "10",
+    argv = ["--synthetic", "6", "--tiny", "--synthetic_classes", "2", "--output_dir", out, "--train_batch_size", "1", "--engine_batch", "4", "--steps", "10",
             "--total_split", str(total), "--split", str(split), "--num_images_per_prompt", "2", "--guidance_type", "transform_guidance",
             "--guidance_step", "4", "--guidance_period", "2", "--strength", "0.5", "--constraint_value", "0.2",
             "--optimize_targets", "global_prototype-local_prototype", "--K", "3"] + list(extra)
