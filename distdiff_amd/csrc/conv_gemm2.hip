@@ -2,9 +2,9 @@
 //
 // Same math, operand layout, LDS swizzle and epilogue as conv_gemm.hip, restructured for the shapes that
 // dominate the UNet / VAE time:
-//   * 8 waves (512 threads), tile BM x BN in {128x256, 128x320, 256x128} (a 256x256 tile spills: 128 accumulator + ~140 staging/fragment VGPRs): 1.3-2x the arithmetic intensity of the
+//   * 8 waves (512 threads), tile BM x BN in {128x256, 256x160, 256x128}, 3 LDS stages (a 256x256 tile spills: 128 accumulator + ~140 staging/fragment VGPRs): 1.3-2x the arithmetic intensity of the
 //     128x128 tile, so the per-XCD L2 no longer bounds the MFMA rate (MI355X: ~56 B/clk/CU of L2 vs 4 kFLOP/clk/CU);
-//     BN = 320 removes the N-padding waste of the SD-1.x channel counts (320/640/960/1280/1920/...).
+//     BN = 160 removes the N-padding waste of the SD-1.x channel counts (320/640/960/1280/1920/...).
 //   * persistent: each workgroup walks a list of (tile, K-split) work items and keeps the LDS-DMA
 //     double-buffered pipeline running ACROSS items, so the first global-load latency and the epilogue of an item
 //     overlap the next item's loads: this is what fixes the shallow-K layers (K = 320: 5 K-steps per tile).
@@ -17,15 +17,18 @@ namespace {
 
 __device__ uint4 g_zero16[4];   // zero page for padded taps / ragged rows (device globals are zero-initialised)
 
-// FE: batched-load epilogue fast paths. They pay off on shallow-K layers (epilogue ~ half the time) but their presence costs the
-// main loop 10-20 % on deep-K layers (same-device A/B, tools/ab_conv.sh: compiler scheduling side effect), hence two instantiations.
-template <int WM, int WN, int TM, int TN, bool FE>
-__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
+template <int WM, int WN, int TM, int TN, int NS, bool FE>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int RPT = 64;       // tile rows per staging pass: 512 threads x 16 B = 64 rows of 128 B
-  constexpr int AV = BM / RPT, BV = BN / RPT;
-  static_assert(WM * WN == 8 && BM % RPT == 0 && BN % RPT == 0, "bad tile");
+  constexpr int NW = WM * WN;   // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512-register budget, 128x128+ per wave)
+  constexpr int NT = NW * 64;
+  constexpr int RPT = NW * 8;   // tile rows per full staging pass: NT threads x 16 B = RPT rows of 128 B
+  constexpr int AV = BM / RPT;  // A passes (all full)
+  constexpr int BV = (BN + RPT - 1) / RPT;          // W passes; the last one may be a half pass (32 rows, lanes 0-31 of every wave)
+  constexpr bool B_HALF = (BN % RPT) == RPT / 2;
+  static_assert((NW == 8 || NW == 4) && BM % RPT == 0 && (BN % RPT == 0 || B_HALF) && (NS == 2 || NS == 3), "bad tile");
   constexpr int BUF_BYTES = (BM + BN) * 128;
+  constexpr int DMA_PER_STAGE = AV + BV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -60,9 +63,16 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
   // linearly, so the XOR swizzle is applied on the SOURCE side: lane (row = lane>>3, physical slot = lane&7) fetches
   // logical K-slot (lane&7) ^ (row&7). Out-of-image taps / ragged rows read a 16-byte zero page instead.
   const int ps = lane & 7;
-  const int j = ps ^ ((lane >> 3) & 7);       // logical 16-byte K-slot this lane fetches
-  const int r0 = tid >> 3;                    // tile row of staging pass 0 (row & 7 == (lane >> 3) & 7)
+  const int j = ps ^ ((lane >> 3) & 7);       // logical 16-byte K-slot this lane fetches (full passes: row & 7 == (lane >> 3) & 7)
+  const int r0 = tid >> 3;                    // tile row of staging pass 0
+  const int rh = wave * 4 + (lane >> 3);      // row inside a half pass (lanes 0-31 only)
+  const int jh = ps ^ (rh & 7);
   const bool fast = uniform_tap && shift == 0 && p.ntaps <= 32;
+  // the per-tap offset table lives in LDS: a global load inside the pipeline would force s_waitcnt vmcnt(0)
+  // (vmcnt retires in order) and drain the in-flight DMA stages
+  int* taps = (int*)(smem + NS * BUF_BYTES);
+  for (int t = tid; t < p.ntaps; t += NT) taps[t] = p.taptab[t];
+  __syncthreads();
   int lw = w_first, l_kt = 0, l_kend = 0;
   int pixb[AV], iy0[AV], ix0[AV];             // general path
   unsigned tapmask[AV];                       // fast path: bit t = tap t is inside the image for this row
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
         if (fast) {
           pb = ((b * p.H + y0) * p.W + x0) * p.x_ld;     // element offset of the centre pixel
           for (int t = 0; t < p.ntaps; ++t) {
-            const int e = p.taptab[t];
+            const int e = taps[t];
             const int yy = y0 + ((e >> 6) & 63) - 32, xx = x0 + (e & 63) - 32;
             tm |= (yy >= 0 && xx >= 0 && yy < p.H && xx < p.W) ? (1u << t) : 0u;
           }
@@ -100,8 +110,9 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      const int n = n0 + r0 + RPT * i;
-      wrow[i] = n < p.N ? (unsigned)n * (unsigned)p.K + (unsigned)(j * 8) : 0xffffffffu;
+      const bool half = B_HALF && i == BV - 1;
+      const int n = n0 + RPT * i + (half ? rh : r0);
+      wrow[i] = n < p.N ? (unsigned)n * (unsigned)p.K + (unsigned)((half ? jh : j) * 8) : 0xffffffffu;
     }
   };
   auto issue_step = [&](int buf) {   // enqueue the LDS-DMA of K-step l_kt of the loader's item into buffer `buf`
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
     if (fast) {
       const int chunk = kt / p.ntaps;                        // wave-uniform; K order = (64-channel chunk, tap)
       const int tap = kt - chunk * p.ntaps;
-      const int e = p.taptab[tap];
+      const int e = taps[tap];
       const int tapoff = ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld + chunk * 64 + j * 8;
 #pragma unroll
       for (int i = 0; i < AV; ++i) {
@@ -127,14 +138,14 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
         const int chunk = kt / p.ntaps;
         const int tap = kt - chunk * p.ntaps;
         coff = chunk * 64 + j * 8;
-        e = p.taptab[tap];
+        e = taps[tap];
         ev = true;
       } else {
         const int k8 = kt * 8 + j;
         const int tap = k8 / cin8;
         ev = tap < p.ntaps;
         coff = (k8 - tap * cin8) * 8;
-        e = p.taptab[ev ? tap : 0];
+        e = taps[ev ? tap : 0];
       }
       const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
 #pragma unroll
@@ -151,8 +162,16 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
       const bf16_t* src = wrow[i] != 0xffffffffu ? p.w + ((size_t)wrow[i] + (size_t)kt * 64) : (const bf16_t*)g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(Bbase + i * (RPT * 128)), 16, 0, 0);
+      if (B_HALF && i == BV - 1) {
+        // half pass: every wave moves 4 rows with its lanes 0-31 (same DMA count in every wave, so counted vmcnt waits are uniform)
+        if (lane < 32)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(smem + buf * BUF_BYTES + BM * 128 + i * (RPT * 128) + wave * 512),
+                                           16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Bbase + i * (RPT * 128)), 16, 0, 0);
+      }
     }
   };
   // advance the loader to the next K-step; returns false when the work list is exhausted
@@ -318,23 +337,40 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
     }
   };
 
-  // ---- pipeline: loader one K-step ahead of the compute iterator, across work items.
-  // __syncthreads() carries the vmcnt(0) that retires the DMA (an LDS-DMA is a pending LDS write for the fence), so a
-  // buffer is read one barrier after its DMA was issued and re-filled one barrier after its last read.
+  // ---- pipeline: NS = 3 LDS stages, the loader runs two K-steps ahead of the compute iterator, across work items.
+  // A stage is read one barrier after the counted s_waitcnt that retires its DMA and re-filled one barrier after its last
+  // read. vmcnt counts every VMEM op of the wave in issue order, so after an epilogue (whose loads/stores interleave with
+  // the DMAs) the iteration drains with vmcnt(0) instead of the counted wait.
+  auto wait_dma = [&](bool keep_one_stage) {
+    if (NS == 3 && keep_one_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   setup_loader(lw);
   issue_step(0);
   bool more = advance_loader();
-  __syncthreads();
+  bool issued = false;
+  if (NS == 3 && more) { issue_step(1); more = advance_loader(); issued = true; }
+  wait_dma(issued);
   int cw = w_first;                                   // compute iterator
   int c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
   zero_acc();
-  int cur = 0;
+  int cur = 0, fill = NS - 1;                         // stage being computed / stage the next DMA goes to
   while (true) {
-    if (more) issue_step(cur ^ 1);
+    issued = false;
+    const bool issue_first = (NW == 8) ? (wave < 4) : true;   // SIMD partners run DMA issue and MFMAs in opposite order
+    const bool had_more = more;
+    const int fill_now = fill;
+    if (had_more) { issued = true; fill = fill == NS - 1 ? 0 : fill + 1; }
+    if (had_more && issue_first) issue_step(fill_now);
     compute(cur);
-    bool done = false;
+    if (had_more && !issue_first) issue_step(fill_now);
+    if (had_more) more = advance_loader();
+    bool done = false, drained = false;
     if (--c_left == 0) {
       epilogue(cw);
+      drained = true;
       cw += Gx;
       if (cw >= w_end) done = true;
       else {
@@ -343,28 +379,28 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmParams p) {
       }
     }
     if (done) break;
-    if (more) more = advance_loader();
-    __syncthreads();
-    cur ^= 1;
+    wait_dma(issued && !drained);
+    cur = cur == NS - 1 ? 0 : cur + 1;
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool FE>
+template <int WM, int WN, int TM, int TN, int NS, bool FE>
 hipError_t run_big_fe(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = NS * (BM + BN) * 128 + 256;   // + per-tap table (<= 64 taps)
+  static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, FE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int W = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit;
   int G = W < 256 ? (W + 7) / 8 * 8 : 256;
-  hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN, FE>), dim3(G), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE>), dim3(G), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS>
 hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
   const int steps_per_item = (p.K / 64 + p.ksplit - 1) / p.ksplit;
-  return steps_per_item <= 24 ? run_big_fe<WM, WN, TM, TN, true>(p, stream) : run_big_fe<WM, WN, TM, TN, false>(p, stream);
+  return steps_per_item <= 24 ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
 }
 
 }  // namespace
@@ -374,22 +410,23 @@ int conv_gemm_big_config(int M, int N, int K, int flags) {
   if (M < 1024 || N < 64 || K < 128) return 0;
   const bool geglu = (flags & CF_GEGLU) != 0;
   if (N <= 128) return 3;                          // 256 x 128
-  if (!geglu && N % 320 == 0 && (N % 256 != 0 || N == 1280)) return 2;   // 128 x 320
+  if (!geglu && N % 160 == 0 && (N % 256 != 0 || N == 1280)) return 2;   // 256 x 160
   if (N % 256 == 0 || N >= 1024) return 1;         // 128 x 256
-  if (!geglu && N % 320 == 0) return 2;
+  if (!geglu && N % 160 == 0) return 2;
   return 0;
 }
 
 void conv_gemm_big_tile(int cfg, int* bm, int* bn) {
-  *bm = cfg == 3 ? 256 : 128;
-  *bn = cfg == 1 ? 256 : cfg == 2 ? 320 : 128;
+  *bm = cfg == 1 ? 128 : 256;
+  *bn = cfg == 1 ? 256 : cfg == 2 ? 160 : 128;
 }
 
 hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream) {
   switch (cfg) {
-    case 1: return run_big<2, 4, 4, 4>(p, stream);
-    case 2: return run_big<2, 4, 4, 5>(p, stream);
-    case 3: return run_big<4, 2, 4, 4>(p, stream);
+    // three LDS stages + counted vmcnt + partner-wave stagger: +0..7 % over two stages in same-device A/B (tools/ab_conv.sh)
+    case 1: return run_big<2, 4, 4, 4, 3>(p, stream);    // 128 x 256, 8 waves
+    case 2: return run_big<4, 2, 4, 5, 3>(p, stream);    // 256 x 160, 8 waves
+    case 3: return run_big<4, 2, 4, 4, 3>(p, stream);    // 256 x 128, 8 waves
     default: return hipErrorInvalidValue;
   }
 }
