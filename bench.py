@@ -99,6 +99,26 @@ def unet_flops_per_sample(cfg):
     return _UNET_FLOPS.get("v", 803.3e9)
 
 
+def recorded_traffic(B, config):
+    """HBM bytes per conv launch from the committed PMC passes (profiles/, tools/pmc_summary.py).
+
+    PMC collection needs rocprofv3 around the whole process, so it cannot run inside the timed region; the
+    number is only attached when the committed passes were taken on this exact workload (same batch)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_b%d_pmc_traffic.json" % B)
+    if config != "sd15" or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        t = json.load(f)
+    byts = launches = 0.0
+    for fam in ("conv_gemm_big_kernel", "conv_gemm_kernel", "splitk"):
+        if fam in t:
+            byts += t[fam]["hbm_fetch_bytes_corrected"] + t[fam]["hbm_write_bytes"]
+            if fam != "splitk":
+                launches += t[fam]["launches"]
+    return {"traffic": byts / max(launches, 1.0), "traffic_unit": "HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": "profiles/" + os.path.basename(path) + " (separate rocprofv3 --pmc passes of this command)"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +237,7 @@ def main():
                                "traffic": None, "launches": cv["ops"], "avg_launch_ms": cv["ms"] / max(cv["ops"], 1),
                                "algorithmic_flops_per_launch": cv["flops"] / max(cv["ops"], 1),
                                "family_ms": {k: v["ms"] for k, v in prof.items()}}
+            out["roofline"].update(recorded_traffic(B, a.config))
         if world == 1 and not a.no_cpu_baseline and a.config == "sd15":
             try:
                 wcpu = weights
