@@ -67,7 +67,7 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int), ("scale", C.c_float),
                 ("d_o", vp), ("lddo", C.c_int), ("dq", vp), ("dk", vp), ("dv", vp),
-                ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("delta", vp), ("accumulate_dq", C.c_int)]
+                ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("delta", vp), ("accumulate_dq", C.c_int), ("causal", C.c_int)]
 
 
 CF_BIAS, CF_RES, CF_RELU, CF_GEGLU, CF_OUT_F32, CF_MASK, CF_RES_F32, CF_GEGLU_RAW = 1, 2, 4, 8, 16, 32, 64, 128
@@ -84,7 +84,7 @@ ENGINE_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
     "dd_set_schedule", "dd_add_noise", "dd_denoise_step", "dd_transform_guidance", "dd_direct_guidance", "dd_decode",
     "dd_expand", "dd_image_to_u8", "dd_guide_encode", "dd_unet_forward", "dd_unet_vjp", "dd_decode_vjp", "dd_guide_vjp",
-    "dd_set_prompt", "dd_debug_tensor", "dd_debug_num_tensors", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
+    "dd_set_prompt", "dd_vae_encode", "dd_text_encode", "dd_debug_tensor", "dd_debug_num_tensors", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
 ]
 
 

@@ -44,6 +44,19 @@ class VAEConfig:
 
 
 @dataclass
+class TextConfig:
+    """CLIPTextModel of the SD-1.x repo (text_encoder/config.json: CLIP ViT-L/14 text tower)."""
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 77
+    hidden_act: str = "quick_gelu"
+    layer_norm_eps: float = 1e-5
+
+
+@dataclass
 class GuideConfig:
     arch: str = "resnet50"
     stem_channels: int = 64
@@ -77,6 +90,7 @@ class EngineConfig:
     unet: UNetConfig = field(default_factory=UNetConfig)
     vae: VAEConfig = field(default_factory=VAEConfig)
     guide: GuideConfig = field(default_factory=GuideConfig)
+    text: TextConfig = field(default_factory=TextConfig)
     scheduler: SchedulerConfig = field(default_factory=SchedulerConfig)
     latent_size: int = 64              # 512 / 8
     text_len: int = 77
@@ -98,6 +112,8 @@ def tiny_config(latent_size=16, max_batch=2):
                         cross_attention_dim=64, norm_num_groups=8),
         vae=VAEConfig(block_out_channels=(32, 64, 64, 64), layers_per_block=1, norm_num_groups=8),
         guide=GuideConfig(stem_channels=16, planes=(16, 32, 32, 64), blocks=(1, 2, 1, 1), input_size=56),
+        text=TextConfig(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                        max_position_embeddings=13),
         latent_size=latent_size, text_len=13, max_batch=max_batch)
 
 
@@ -128,6 +144,12 @@ def from_model_dir(path, latent_size=64, max_batch=1):
         cfg.vae.layers_per_block = v.get("layers_per_block", cfg.vae.layers_per_block)
         cfg.vae.scaling_factor = v.get("scaling_factor", cfg.vae.scaling_factor)
         cfg.vae.norm_num_groups = v.get("norm_num_groups", cfg.vae.norm_num_groups)
+    t = _load("text_encoder/config.json")
+    if t:
+        for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                  "max_position_embeddings", "hidden_act", "layer_norm_eps"):
+            if k in t:
+                setattr(cfg.text, k, t[k])
     s = _load("scheduler/scheduler_config.json")
     if s:
         for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one",

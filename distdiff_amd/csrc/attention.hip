@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
   f32x4 o[QT][DTW];
   float mrun[QT], lsum[QT];
+  int klim[QT];   // first masked key of this lane's query row
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
+    klim[qt] = p.causal ? min(p.Nk, qrow[qt] + 1) : p.Nk;
     mrun[qt] = -INFINITY; lsum[qt] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DTW; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
       }
     }
-    const bool partial = k0 + KT > p.Nk;     // wave-uniform: only the last tile of a ragged key count needs masking
+    // wave-uniform: only the last tile of a ragged key count (or a causal mask, CLIP text encoder) needs masking
+    const bool partial = k0 + KT > p.Nk || p.causal;
     bf16x8 pf[QT][NC];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (k0 + kt * 16 + 4 * g + r >= p.Nk) st[qt][kt][r] = -INFINITY;
+            if (k0 + kt * 16 + 4 * g + r >= klim[qt]) st[qt][kt][r] = -INFINITY;
       }
       float mx = st[qt][0][0];
 #pragma unroll

@@ -485,6 +485,56 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, const f
 }
 __global__ void scale_rows_kernel(float* x, const float* s, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) x[i] *= s[0]; }
 
+// ---- f-2: stage before the loop (dataloader.py:633-661, 750-811) -----------------------------------------------
+// CLIPTextEmbeddings: out[b*T + t, :] = token_embedding[ids[b, t]] + position_embedding[t]
+__global__ void clip_embed_kernel(const int* ids, const float* tok, const float* pos, bf16_t* out, int ld, int rows, int T, int C,
+                                  int vocab) {
+  const size_t total = (size_t)rows * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const int r = (int)(i / C);
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    out[(size_t)r * ld + c] = f2bf(tok[(size_t)id * C + c] + pos[(size_t)(r % T) * C + c]);
+  }
+}
+// CLIP MLP activation: kind 0 quick_gelu x*sigmoid(1.702x) (SD-1.x text encoder), kind 1 erf-GELU
+__global__ void act_bf16_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, int kind) {
+  const size_t total = (size_t)M * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const float v = bf2f(x[r * ldx + c]);
+    const float o = kind == 0 ? v / (1.f + __expf(-1.702f * v)) : 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    y[r * ldy + c] = f2bf(o);
+  }
+}
+// DiagonalGaussianDistribution.sample() * scaling_factor (dataloader.py:808-809): moments NHWC fp32 [B*HW, ld] = (mean | logvar),
+// logvar clamped to [-30, 20]; noise NCHW fp32 or null (-> the mode).  latents NCHW fp32; optional moments_out NCHW [B, 2C, HW].
+__global__ void vae_sample_kernel(const float* mom, int ld, const float* noise, float* lat, float* mom_out, int B, int C, int HW,
+                                  float scale) {
+  const size_t total = (size_t)B * C * HW;
+  GRID_STRIDE(i, total) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const size_t row = ((size_t)b * HW + pix) * ld;
+    const float mean = mom[row + c];
+    const float logvar = fminf(fmaxf(mom[row + C + c], -30.f), 20.f);
+    const float n = noise ? noise[i] : 0.f;
+    lat[i] = (mean + __expf(0.5f * logvar) * n) * scale;
+    if (mom_out) {
+      mom_out[((size_t)b * 2 * C + c) * HW + pix] = mean;
+      mom_out[((size_t)b * 2 * C + C + c) * HW + pix] = logvar;
+    }
+  }
+}
+// bf16 rows [M, ld] -> fp32 rows [M, C]
+__global__ void rows_bf16_to_f32_kernel(const bf16_t* x, int ld, float* y, int M, int C) {
+  const size_t total = (size_t)M * C;
+  GRID_STRIDE(i, total) { y[i] = bf2f(x[(i / C) * ld + (i % C)]); }
+}
+
 }  // namespace
 
 #define LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, s, __VA_ARGS__); return hipGetLastError()
@@ -578,4 +628,18 @@ hipError_t launch_linear_f32(const float* x, const float* W, const float* b, flo
   const size_t waves = (size_t)M * N;
   hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, W, b, y, M, N, K, silu_in);
   return hipGetLastError();
+}
+hipError_t launch_clip_embed(const int* ids, const float* tok, const float* pos, bf16_t* out, int ld, int rows, int T, int C, int vocab,
+                            hipStream_t s) {
+  LAUNCH(clip_embed_kernel, (size_t)rows * C, ids, tok, pos, out, ld, rows, T, C, vocab);
+}
+hipError_t launch_act_bf16(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, int kind, hipStream_t s) {
+  LAUNCH(act_bf16_kernel, (size_t)M * C, x, ldx, y, ldy, M, C, kind);
+}
+hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
+                             float scale, hipStream_t s) {
+  LAUNCH(vae_sample_kernel, (size_t)B * C * HW, moments, ld, noise, latents, moments_out, B, C, HW, scale);
+}
+hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s) {
+  LAUNCH(rows_bf16_to_f32_kernel, (size_t)M * C, x, ld, y, M, C);
 }

@@ -54,6 +54,7 @@ T* dev_upload(const std::vector<T>& h) {
 // ---------------------------------------------------------------------------------------------------
 struct ConvW {
   int Cout = 0, Cin = 0, KH = 1, KW = 1, pad = 0;
+  int pad_br = 0;              // extra zero rows/cols at the bottom/right only (AutoencoderKL encoder downsample: F.pad (0,1,0,1))
   bool geglu = false;
   PackedConv sf{}, sb{};
   bf16_t* w_fwd = nullptr; int* tap_fwd = nullptr;
@@ -76,7 +77,7 @@ struct Tn {              // activation tensor or channel view
   bool f32 = false, grad = false;
 };
 
-enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP };
+enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT };
 
 struct Op {
   OpKind kind;
@@ -86,6 +87,7 @@ struct Op {
   int stride = 1, up = 0, relu = 0, out_f32 = 0, use_table = 0;
   int G = 0, silu = 0; float eps = 0;
   int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
+  int causal = 0, act_kind = 0;
   size_t stats_off = 0;  // fp32 stats / lse in the activation slab
   // backward plan
   bool x_acc = false, res_acc = false, x2_acc = false;
@@ -175,6 +177,12 @@ struct dd_engine {
 
   Program unet, vae, guide;
   int unet_in = -1, unet_out = -1, vae_in = -1, vae_out = -1, guide_in = -1, guide_feat = -1;
+  // f-2: the stage before the loop (built when the weights are present)
+  Program venc, text;
+  int venc_in = -1, venc_out = -1, text_in = -1, text_out = -1;
+  char* venc_slab = nullptr; char* text_slab = nullptr;
+  float* tok_emb = nullptr; float* pos_emb = nullptr; int text_vocab = 0, text_hidden = 0, text_batch = 0;
+  int* text_ids = nullptr;
   struct CrossSlot { ConvW* wk; ConvW* wv; int C; };
   std::vector<CrossSlot> cross_slots;
   std::vector<std::pair<bf16_t*, bf16_t*>> cross_kv;  // device K,V [2B*text_len, C] per slot
@@ -333,7 +341,7 @@ struct Builder {
            int y_into = -1, bool keep_raw = true) {
     const Tn& tx = P.t[x];
     const int Hl = tx.H << up, Wl = tx.W << up;
-    const int Ho = (Hl + 2 * w->pad - w->KH) / stride + 1, Wo = (Wl + 2 * w->pad - w->KW) / stride + 1;
+    const int Ho = (Hl + 2 * w->pad + w->pad_br - w->KH) / stride + 1, Wo = (Wl + 2 * w->pad + w->pad_br - w->KW) / stride + 1;
     const int Cy = w->geglu ? w->Cout / 2 : w->Cout;
     int y = y_into >= 0 ? y_into : P.tensor(tx.B, Ho, Wo, Cy, true, out_f32 != 0);
     Op op; op.kind = OP_CONV; op.x = x; op.y = y; op.res = res; op.cw = w; op.stride = stride; op.up = up; op.relu = relu;
@@ -372,11 +380,11 @@ struct Builder {
     return y;
   }
   // self attention: q,k,v are views ; cross attention: k,v come from slot (constant, no grad)
-  int attn(int q, int k, int v, int heads, int Nq, int Nk, int cross_slot) {
+  int attn(int q, int k, int v, int heads, int Nq, int Nk, int cross_slot, int causal = 0) {
     const Tn& tq = P.t[q];
     int y = P.tensor(tq.B, tq.H, tq.W, tq.C);
     Op op; op.kind = OP_ATTN; op.q = q; op.k = k; op.v = v; op.y = y; op.heads = heads; op.D = tq.C / heads; op.Nq = Nq; op.Nk = Nk;
-    op.cross_slot = cross_slot;
+    op.cross_slot = cross_slot; op.causal = causal;
     op.stats_off = P.fp32_block((size_t)tq.B * heads * Nq * 2);  // lse + delta
     op.flops = 4.0 * tq.B * heads * (double)Nq * Nk * op.D;
     P.ops.push_back(op);
@@ -386,6 +394,13 @@ struct Builder {
     const Tn& ta = P.t[a]; const Tn& tb = P.t[b];
     int y = P.tensor(ta.B, ta.H, ta.W, ta.C + tb.C);
     Op op; op.kind = OP_CONCAT; op.x = a; op.x2 = b; op.y = y;
+    P.ops.push_back(op);
+    return y;
+  }
+  int act(int x, int kind) {   // forward-only programs (text encoder MLP)
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    Op op; op.kind = OP_ACT; op.x = x; op.y = y; op.act_kind = kind;
     P.ops.push_back(op);
     return y;
   }
@@ -427,6 +442,7 @@ void plan_backward(Program& P) {
       case OP_GN: case OP_LN: case OP_MAXPOOL: case OP_GAP:
         op.x_acc = mark(op.x);
         break;
+      case OP_ACT: throw std::runtime_error("OP_ACT has no backward (forward-only programs)");
       case OP_ATTN:
         mark(op.q);
         if (op.cross_slot < 0) { mark(op.k); mark(op.v); }
@@ -509,6 +525,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         }
         p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
+        p.causal = op.causal;
         HIPCHK(launch_attention_fwd(p, c.s));
         if (c.flops) *c.flops += op.flops;
       } break;
@@ -520,6 +537,10 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
       case OP_MAXPOOL: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         HIPCHK(launch_maxpool3x3s2(act_ptr(c, x), act_ptr(c, y), x.B, x.H, x.W, x.C, c.s));
+      } break;
+      case OP_ACT: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_act_bf16(act_ptr(c, x), x.ld, act_ptr(c, y), y.ld, x.rows, x.C, op.act_kind, c.s));
       } break;
       case OP_GAP: break;
     }
@@ -636,7 +657,7 @@ void run_bwd(const Program& P, const Ctx& c) {
         if (op.x_acc) throw std::runtime_error("maxpool backward accumulate unsupported");
         HIPCHK(launch_maxpool3x3s2_bwd(act_ptr(c, x), grad_ptr(c, y), grad_ptr(c, x), x.B, x.H, x.W, x.C, c.s));
       } break;
-      case OP_GAP: break;
+      case OP_GAP: case OP_ACT: break;
     }
   }
 }
@@ -780,6 +801,91 @@ void build_vae(dd_engine* E) {
   h = b.gn(h, make_norm(E, m, "decoder.conv_norm_out"), G, eps, 1);
   E->vae_out = b.conv(h, make_conv(E, m, "decoder.conv_out", 1));
   if (P.want_grad) plan_backward(P);
+}
+
+// f-2: AutoencoderKL.encode (dataloader.py:808) -- Encoder: conv_in, DownEncoderBlock2D x levels (resnets +
+// stride-2 conv with F.pad (0,1,0,1)), mid Res-Attn-Res, GN+SiLU+conv_out, quant_conv -> moments (mean | logvar) fp32.
+// Forward only; built when the state dict carries encoder.* keys.
+void build_vae_encoder(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->venc;
+  P.want_grad = false;
+  Builder b(E, P);
+  const int B = c.max_batch, S = c.latent_size << (c.vae_levels - 1), G = c.vae_groups, nl = c.vae_levels;
+  const float eps = c.vae_eps;
+  const std::string m = "vae";
+  E->venc_in = P.tensor(B, S, S, c.vae_out_channels);
+  int h = b.conv(E->venc_in, make_conv(E, m, "encoder.conv_in", 1));
+  char buf[128];
+  for (int i = 0; i < nl; ++i) {
+    for (int j = 0; j < c.vae_layers_per_block; ++j) {
+      snprintf(buf, sizeof buf, "encoder.down_blocks.%d.resnets.%d", i, j);
+      h = build_resnet(b, m, buf, h, G, eps, false);
+    }
+    if (i < nl - 1) {
+      snprintf(buf, sizeof buf, "encoder.down_blocks.%d.downsamplers.0.conv", i);
+      ConvW* w = make_conv(E, m, buf, 0);
+      w->pad_br = 1;
+      h = b.conv(h, w, 2);
+    }
+  }
+  h = build_resnet(b, m, "encoder.mid_block.resnets.0", h, G, eps, false);
+  {
+    const std::string a = "encoder.mid_block.attentions.0";
+    const int C = P.t[h].C, HW = P.t[h].H * P.t[h].W;
+    int n = b.gn(h, make_norm(E, m, a + ".group_norm"), G, eps, 0);
+    int qkv = b.conv(n, make_conv_cat(E, m, {a + ".to_q", a + ".to_k", a + ".to_v"}, true));
+    int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+    int o = b.attn(q, k, v, 1, HW, HW, -1);
+    h = b.conv(o, make_conv(E, m, a + ".to_out.0", 0), 1, 0, h);
+  }
+  h = build_resnet(b, m, "encoder.mid_block.resnets.1", h, G, eps, false);
+  h = b.gn(h, make_norm(E, m, "encoder.conv_norm_out"), G, eps, 1);
+  h = b.conv(h, make_conv(E, m, "encoder.conv_out", 1));
+  E->venc_out = b.conv(h, make_conv(E, m, "quant_conv", 0), 1, 0, -1, 0, /*out_f32=*/1);
+}
+
+// f-2: CLIPTextModel (transformers; dataloader.py:633-646 `text_encoder(input_ids)[0]`): token + position embeddings, pre-LN
+// transformer layers with causal self-attention and a quick_gelu (or erf-GELU) MLP, final LayerNorm.  Forward only.
+void build_text_encoder(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->text;
+  P.want_grad = false;
+  Builder b(E, P);
+  const std::string m = "text", tm = "text_model.";
+  const HostTensor& tok = E->get(m, tm + "embeddings.token_embedding.weight");
+  const HostTensor& pos = E->get(m, tm + "embeddings.position_embedding.weight");
+  E->text_vocab = (int)tok.shape[0]; E->text_hidden = (int)tok.shape[1];
+  if ((int)pos.shape[0] < c.text_len) throw std::runtime_error("text encoder has fewer positions than text_len");
+  if (E->text_hidden != c.unet_cross_dim) throw std::runtime_error("text encoder width != UNet cross_attention_dim");
+  const int heads = c.text_heads > 0 ? c.text_heads : 12;
+  if (E->text_hidden % heads) throw std::runtime_error("text hidden size is not divisible by text_heads");
+  E->tok_emb = (float*)E->dmalloc(tok.data.size() * 4, false);
+  HIPCHK(hipMemcpy(E->tok_emb, tok.data.data(), tok.data.size() * 4, hipMemcpyHostToDevice));
+  E->pos_emb = (float*)E->dmalloc(pos.data.size() * 4, false);
+  HIPCHK(hipMemcpy(E->pos_emb, pos.data.data(), pos.data.size() * 4, hipMemcpyHostToDevice));
+  const int Bt = 2 * c.max_batch, T = c.text_len, C = E->text_hidden;
+  const float eps = c.text_eps > 0.f ? c.text_eps : 1e-5f;
+  E->text_batch = Bt;
+  E->text_ids = (int*)E->dmalloc((size_t)Bt * T * 4);
+  int x = P.tensor(Bt, T, 1, C);
+  E->text_in = x;
+  char buf[160];
+  for (int l = 0;; ++l) {
+    snprintf(buf, sizeof buf, "%sencoder.layers.%d", tm.c_str(), l);
+    const std::string p = buf;
+    if (!E->has(m, p + ".layer_norm1.weight")) break;
+    int h = b.ln(x, make_norm(E, m, p + ".layer_norm1"), eps);
+    int qkv = b.conv(h, make_conv_cat(E, m, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, true));
+    int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+    int o = b.attn(q, k, v, heads, T, T, -1, /*causal=*/1);
+    x = b.conv(o, make_conv(E, m, p + ".self_attn.out_proj", 0), 1, 0, x);
+    h = b.ln(x, make_norm(E, m, p + ".layer_norm2"), eps);
+    h = b.conv(h, make_conv(E, m, p + ".mlp.fc1", 0));
+    h = b.act(h, c.text_act);
+    x = b.conv(h, make_conv(E, m, p + ".mlp.fc2", 0), 1, 0, x);
+  }
+  E->text_out = b.ln(x, make_norm(E, m, tm + "final_layer_norm"), eps);
 }
 
 void build_guide(dd_engine* E) {
@@ -969,6 +1075,10 @@ int dd_finalize_weights(dd_engine* E) {
     build_unet(E);
     build_vae(E);
     build_guide(E);
+    const bool have_venc = E->has("vae", "encoder.conv_in.weight");
+    const bool have_text = E->has("text", "text_model.embeddings.token_embedding.weight");
+    if (have_venc) build_vae_encoder(E);
+    if (have_text) build_text_encoder(E);
     // time embedding MLP weights (fp32, setup-time only)
     auto up = [&](const char* key) {
       const HostTensor& t = E->get("unet", key);
@@ -1001,7 +1111,11 @@ int dd_finalize_weights(dd_engine* E) {
       E->grad_slab = (char*)E->dmalloc(g);
       for (auto& t : E->guide.t) t.goff += E->vae.grad_bytes;
     }
-    E->partial_cap = std::max({E->unet.scratch_partial, E->vae.scratch_partial, E->guide.scratch_partial, (size_t)1 << 20});
+    // encoder programs run before the loop: the image encoder borrows the decoder slab of instance 0 when it fits
+    if (have_venc) E->venc_slab = E->venc.act_bytes <= E->vae.act_bytes ? E->inst[0].vae : (char*)E->dmalloc(E->venc.act_bytes);
+    if (have_text) E->text_slab = (char*)E->dmalloc(E->text.act_bytes);
+    E->partial_cap = std::max({E->unet.scratch_partial, E->vae.scratch_partial, E->guide.scratch_partial, E->venc.scratch_partial,
+                               E->text.scratch_partial, (size_t)1 << 20});
     E->scratch_partial = (char*)E->dmalloc(E->partial_cap, false);
     E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, (size_t)256});
     E->scratch_tmp = (char*)E->dmalloc(E->tmp_cap);
@@ -1156,6 +1270,47 @@ int dd_decode(dd_engine* E, const float* z, float* image_out, int denormalize, i
     const Tn& img = E->vae.t[E->vae_out];
     HIPCHK(launch_nhwc_to_nchw_f32(E->inst[0].vae + img.off, 0, image_out, B, c.vae_out_channels, img.H, img.W, img.ld,
                                    denormalize ? 0.5f : 1.f, denormalize ? 0.5f : 0.f, denormalize, 0.f, 1.f, s));
+  });
+}
+
+int dd_vae_encode(dd_engine* E, const float* images, const float* noise, float* latents_out, float* moments_out, int B, void* stream) {
+  if (!E || !images || !latents_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    if (!E->venc_slab) throw std::runtime_error("no VAE encoder weights were loaded (vae/encoder.* keys)");
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    Run r{E, s, B};
+    Ctx ctx = r.ctx(E->venc, E->venc_slab);
+    ctx.stash = false;
+    const Tn& in = E->venc.t[E->venc_in];
+    HIPCHK(launch_nchw_f32_to_nhwc_bf16(images, act_ptr(ctx, in), B, c.vae_out_channels, in.H, in.W, in.ld, in.ld, 0, 1.f, s));
+    run_fwd(E->venc, ctx);
+    const Tn& mo = E->venc.t[E->venc_out];
+    HIPCHK(launch_vae_sample((const float*)(ctx.act + mo.off), mo.ld, noise, latents_out, moments_out, B, c.vae_latent_channels,
+                             mo.H * mo.W, c.vae_scaling_factor, s));
+  });
+}
+
+int dd_text_encode(dd_engine* E, const int* input_ids, float* embeds_out, int n, void* stream) {
+  if (!E || !input_ids || !embeds_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    if (!E->finalized) throw std::runtime_error("dd_finalize_weights has not been called");
+    if (!E->text_slab) throw std::runtime_error("no text encoder weights were loaded (text/text_model.* keys)");
+    if (n < 1 || n > E->text_batch) throw std::runtime_error("dd_text_encode: n must be in [1, 2*max_batch]");
+    const dd_config& c = E->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = c.text_len, Cc = E->text_hidden;
+    HIPCHK(hipMemsetAsync(E->text_ids, 0, (size_t)E->text_batch * T * 4, s));
+    HIPCHK(hipMemcpyAsync(E->text_ids, input_ids, (size_t)n * T * 4, hipMemcpyDeviceToDevice, s));
+    Run r{E, s, E->text_batch};
+    Ctx ctx = r.ctx(E->text, E->text_slab);
+    ctx.stash = false;
+    const Tn& in = E->text.t[E->text_in];
+    HIPCHK(launch_clip_embed(E->text_ids, E->tok_emb, E->pos_emb, act_ptr(ctx, in), in.ld, in.rows, T, Cc, E->text_vocab, s));
+    run_fwd(E->text, ctx);
+    const Tn& o = E->text.t[E->text_out];
+    HIPCHK(launch_rows_bf16_to_f32(act_ptr(ctx, o), o.ld, embeds_out, n * T, Cc, s));
   });
 }
 

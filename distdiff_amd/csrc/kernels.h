@@ -106,6 +106,7 @@ struct AttnParams {
   int lddq, lddk, lddv;
   float* delta;                             // [B][H][Nq] scratch: rowsum(dO*O)
   int accumulate_dq;                        // unused for now (dq is written)
+  int causal;                               // forward only: key j visible to query i iff j <= i (CLIP text encoder)
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);
@@ -182,6 +183,15 @@ hipError_t launch_linear_f32(const float* x, const float* W, const float* b, flo
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s);
 // (x/2+0.5).clamp(0,1)*255+0.5 -> uint8 HWC (output stage, generate_data.py:1227 + save_image quantisation)
 hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s);
+
+// f-2, the stage before the loop (dataloader.py:633-661, 750-811): CLIP token + position embedding gather, CLIP MLP activation
+// (kind 0 quick_gelu, 1 erf-GELU), DiagonalGaussian sample * scaling_factor from fp32 NHWC moments, bf16 rows -> fp32 rows
+hipError_t launch_clip_embed(const int* ids, const float* tok, const float* pos, bf16_t* out, int ld, int rows, int T, int C, int vocab,
+                            hipStream_t s);
+hipError_t launch_act_bf16(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, int kind, hipStream_t s);
+hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
+                             float scale, hipStream_t s);
+hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s);
 
 // ----------------------------------------------------------------------------------------------
 // host-side weight packing (weights.cpp)

@@ -29,6 +29,7 @@ class DDConfig(C.Structure):
         ("guide_expansion", C.c_int), ("guide_input_size", C.c_int), ("guide_bn_eps", C.c_float),
         ("latent_size", C.c_int), ("text_len", C.c_int), ("max_batch", C.c_int),
         ("enable_grad", C.c_int), ("max_guidance_period", C.c_int),
+        ("text_heads", C.c_int), ("text_act", C.c_int), ("text_eps", C.c_float),
     ]
 
 
@@ -63,6 +64,8 @@ def _declare(l):
     l.dd_decode.argtypes = [vp, vp, vp, i, i, vp]
     l.dd_expand.argtypes = [vp, C.POINTER(DDExpandArgs), vp]
     l.dd_guide_encode.argtypes = [vp, vp, vp, i, vp]
+    l.dd_vae_encode.argtypes = [vp, vp, vp, vp, vp, i, vp]
+    l.dd_text_encode.argtypes = [vp, vp, vp, i, vp]
     l.dd_image_to_u8.argtypes = [vp, vp, vp, i, vp]
     l.dd_unet_forward.argtypes = [vp, vp, i, vp, i, vp]
     l.dd_unet_vjp.argtypes = [vp, vp, i, vp, vp, i, vp]
@@ -102,6 +105,8 @@ def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
     c.guide_expansion, c.guide_input_size, c.guide_bn_eps = g.expansion, g.input_size, g.bn_eps
     c.latent_size, c.text_len, c.max_batch = cfg.latent_size, cfg.text_len, cfg.max_batch
     c.enable_grad, c.max_guidance_period = int(enable_grad), int(max_guidance_period)
+    t = cfg.text
+    c.text_heads, c.text_act, c.text_eps = t.num_attention_heads, {"quick_gelu": 0, "gelu": 1}[t.hidden_act], t.layer_norm_eps
     return c
 
 
@@ -124,8 +129,8 @@ class Engine:
         self._h = vp()
         cc = _to_c_config(cfg, enable_grad, max_guidance_period)
         self._chk(self.L.dd_create(C.byref(cc), C.byref(self._h)), "dd_create")
-        for model in ("unet", "vae", "guide"):
-            for key, t in weights[model].items():
+        for model in ("unet", "vae", "guide", "text"):
+            for key, t in weights.get(model, {}).items():
                 if key.startswith("fc.") or key.endswith("num_batches_tracked"):
                     continue
                 a = t.detach().float().contiguous().cpu()
@@ -179,6 +184,26 @@ class Engine:
         assert e.shape[0] == 2 * self.B
         self._chk(self.L.dd_set_prompt(self._h, _p(e), self.B, _stream()), "dd_set_prompt")
         self._keep = [e]
+
+    # ---- stage before the loop (dataloader.py:633-661, 750-811) ------------------
+    def vae_encode(self, images, noise=None, return_moments=False):
+        """`vae.encode(x).latent_dist.sample() * vae.config.scaling_factor` (dataloader.py:808-809).
+        images [B,3,8L,8L] in [-1,1]; noise [B,4,L,L] ~ N(0,1), or None for the distribution's mode."""
+        x = self._f(images)
+        B, L = x.shape[0], self.cfg.latent_size
+        n = self._f(noise) if noise is not None else None
+        lat = torch.empty((B, self.cfg.vae.latent_channels, L, L), device=self.device, dtype=torch.float32)
+        mom = torch.empty((B, 2 * self.cfg.vae.latent_channels, L, L), device=self.device, dtype=torch.float32) if return_moments else None
+        self._chk(self.L.dd_vae_encode(self._h, _p(x), _p(n), _p(lat), _p(mom), B, _stream()), "dd_vae_encode")
+        return (lat, mom) if return_moments else lat
+
+    def text_encode(self, input_ids):
+        """`text_encoder(input_ids)[0]` (dataloader.py:633-646): ids [n, text_len] -> [n, text_len, cross_dim] fp32, n <= 2B."""
+        ids = input_ids.to(self.device, torch.int32).contiguous()
+        n = ids.shape[0]
+        out = torch.empty((n, self.cfg.text_len, self.cfg.unet.cross_attention_dim), device=self.device, dtype=torch.float32)
+        self._chk(self.L.dd_text_encode(self._h, _p(ids), _p(out), n, _stream()), "dd_text_encode")
+        return out
 
     # ---- hot path ------------------------------------------------------------------------------
     def _f(self, t):

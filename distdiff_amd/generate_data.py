@@ -11,8 +11,11 @@ loop (:1130-1236) executed by the MI355X engine (libdistdiff_hip.so) instead of 
 Superset over the reference (documented, defaults reproduce it): `--steps` and `--resolution` are honoured
 (the reference parses but ignores them); `--synthetic N` runs on N seeded synthetic images with
 synthetic weights (no checkpoints / datasets are needed; used by tests and benchmarks).
-Inputs the engine does not produce yet (VAE encoder, CLIP text encoder) are read from the reference's
-own caches: `save/vae_embedding/<dataset>/<model>/image_latents.pt` and `.../text_embeds.pt`.
+The stage before the loop runs on the engine too: image latents come from the reference's cache
+`save/vae_embedding/<dataset>/<model>/image_latents.pt` when it exists and are otherwise produced by the HIP VAE encoder and
+written to that path in the same format (dataloader.py:788-811); class prompts go through the Hugging Face tokenizer of the
+model directory and the HIP CLIP text encoder (dataloader.py:633-661, 780-786).  `--synthetic N --synthetic_encode` drives
+both encoders on seeded synthetic images / token ids.
 """
 import argparse
 import logging
@@ -78,6 +81,8 @@ def parse_args(argv=None):
     # superset
     p.add_argument("--synthetic", type=int, default=0, help="run on N seeded synthetic images with synthetic weights")
     p.add_argument("--synthetic_classes", type=int, default=4)
+    p.add_argument("--synthetic_encode", action="store_true",
+                   help="with --synthetic: produce latents / prompt embeddings with the HIP VAE encoder and CLIP text encoder")
     p.add_argument("--tiny", action="store_true", help="use the tiny test architecture (with --synthetic)")
     p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = max(train_batch_size, 8)); units (image, expand index) are independent")
     p.add_argument("--data_root", type=str, default="data")
@@ -120,8 +125,8 @@ class ExpansionDataset:
                                 targets, names, ["%s/image_%04d.jpg" % (names[int(t)], i) for i, t in enumerate(targets)])
 
     @staticmethod
-    def from_caches(args, cfg):
-        """Caltech-101 listing as dataloader.py:272-315 + the reference's latent cache (dataloader.py:788-796)."""
+    def from_dataset(args, cfg, eng):
+        """Caltech-101 listing as dataloader.py:272-315; latents and prompt embeddings as SDDataset.__init__ (dataloader.py:750-796)."""
         root = os.path.join(args.data_root, "caltech-101", "101_ObjectCategories") if args.dataset == "caltech-101" else \
             os.path.join(args.data_root, args.dataset)
         if not os.path.isdir(root):
@@ -133,14 +138,33 @@ class ExpansionDataset:
                 paths.append(os.path.join(root, c, f))
                 targets.append(ci)
         names = [c.replace("_", " ") for c in classes]                     # dataloader.py:129
-        cache = os.path.join("save", "vae_embedding", args.dataset, args.pretrained_model_name_or_path.replace("/", "--"))
-        lat_p, txt_p = os.path.join(cache, "image_latents.pt"), os.path.join(cache, "text_embeds.pt")
-        if not (os.path.exists(lat_p) and os.path.exists(txt_p)):
-            raise SystemExit("latent/text caches %s, %s not found: the VAE encoder and CLIP text encoder are the next rows to build "
-                             "(SURVEY.md section 8f-2); produce the caches with the reference once, or use --synthetic N" % (lat_p, txt_p))
-        lat = torch.cat([x.float() for x in torch.load(lat_p, map_location="cpu")], dim=0)
-        te = torch.load(txt_p, map_location="cpu")
-        return ExpansionDataset(lat, te["class_embeds"].float(), te["uncond_embeds"].float(), torch.tensor(targets), names, paths)
+        from .preprocess import class_prompt_embeddings, load_or_encode_latents, load_tokenizer
+        # image latents: the reference's cache file if present, else the HIP VAE encoder fills it (dataloader.py:788-796)
+        lat = load_or_encode_latents(eng, args.dataset, args.pretrained_model_name_or_path, paths, args.resolution,
+                                     center_crop=args.center_crop, seed=args.seed or 0)
+        lat = torch.cat([x.float().cpu() for x in lat], dim=0)
+        # class prompts + the empty prompt through the HIP CLIP text encoder (dataloader.py:780-786)
+        tokenizer = load_tokenizer(args.pretrained_model_name_or_path, args.revision)
+        class_embeds, uncond = class_prompt_embeddings(eng, tokenizer, args.dataset, names)
+        return ExpansionDataset(lat, class_embeds, uncond, torch.tensor(targets), names, paths)
+
+    @staticmethod
+    def synthetic_encoded(cfg, eng, n, n_classes, seed):
+        """--synthetic N --synthetic_encode: like `synthetic`, but the latents come from seeded synthetic images through the
+        HIP VAE encoder and the prompt embeddings from seeded token ids through the HIP text encoder (8f-2 path end to end)."""
+        from .preprocess import encode_token_ids
+        base = ExpansionDataset.synthetic(cfg, n, n_classes, seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        S, L, B = 8 * cfg.latent_size, cfg.latent_size, eng.B
+        lat = []
+        for i in range(0, n, B):
+            k = min(B, n - i)
+            x = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+            noise = torch.randn(B, cfg.vae.latent_channels, L, L, generator=g)
+            lat.append(eng.vae_encode(x, noise).cpu()[:k])
+        ids = torch.randint(0, cfg.text.vocab_size, (n_classes + 1, cfg.text_len), generator=g).int()
+        emb = encode_token_ids(eng, ids)
+        return ExpansionDataset(torch.cat(lat), emb[:-1], emb[-1:], base.targets, base.class_names, base.image_paths)
 
 
 def output_path(output_dir, class_name, image_path, image_i):
@@ -266,16 +290,17 @@ def build_engine(args):
     latent = args.resolution // 8
     if args.synthetic:
         cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
-        weights = synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes)
+        weights = synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes, encoders=args.synthetic_encode)
     else:
         path = args.pretrained_model_name_or_path
         if not os.path.isdir(path):
             raise SystemExit("%s is not a local model directory (no network access here); pass a local Hugging Face layout with unet/ and "
                              "vae/ safetensors, or use --synthetic N" % path)
         cfg = from_model_dir(path, latent, B)
-        vae_sd = {k: v for k, v in load_safetensors_dir(path, "vae").items() if k.startswith(("decoder.", "post_quant_conv."))}
         guide = create_model(args.arch, pretrained=False, num_classes=1, weight_path=args.encoder_weight_path)
-        weights = {"unet": load_safetensors_dir(path, "unet"), "vae": vae_sd, "guide": guide.state_dict()}
+        weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": guide.state_dict(),
+                   "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder", ("model.safetensors",)).items()
+                            if "position_ids" not in k}}
     guided = bool(args.guidance_type)
     eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=max(1, args.guidance_period), device=args.device or "cuda:0")
     sched = DDIMSchedule(cfg.scheduler)
@@ -300,14 +325,17 @@ def main(argv=None):
         raise SystemExit("guide arch %r: only resnet50 is built (SURVEY.md section 8f-4)" % args.arch)
     cfg, eng, sched = build_engine(args)
     if args.synthetic:
-        ds = ExpansionDataset.synthetic(cfg, args.synthetic, args.synthetic_classes, seed=args.seed or 0)
+        if args.synthetic_encode:
+            ds = ExpansionDataset.synthetic_encoded(cfg, eng, args.synthetic, args.synthetic_classes, seed=args.seed or 0)
+        else:
+            ds = ExpansionDataset.synthetic(cfg, args.synthetic, args.synthetic_classes, seed=args.seed or 0)
         if args.guidance_type:
             g = torch.Generator().manual_seed(3)
             D = cfg.guide.feature_dim
             Pc = torch.randn(args.synthetic_classes, D, generator=g)
             Pg = torch.randn(args.synthetic_classes, args.K, D, generator=g)
     else:
-        ds = ExpansionDataset.from_caches(args, cfg)
+        ds = ExpansionDataset.from_dataset(args, cfg, eng)
         if args.guidance_type:
             from .prototypes import extract_prototypes_with_encoder
             assert args.encoder_weight_path and os.path.exists(args.encoder_weight_path)       # :1108

@@ -134,7 +134,7 @@ def layernorm(x, gamma, beta, eps, dy=None, stats=None):
     return dx
 
 
-def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True):
+def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False):
     """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors)."""
     L = _lib.lib()
     p = AttnParams()
@@ -143,6 +143,7 @@ def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True):
     p.q, p.k, p.v, p.o, p.lse = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     p.B, p.H, p.Nq, p.Nk, p.D, p.scale = B, H, Nq, Nk, D, scale
+    p.causal = 1 if causal else 0
     check(L.dd_op_attention_fwd(C.byref(p), _stream()), "attn_fwd")
     if d_o is None:
         return o, lse

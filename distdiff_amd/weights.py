@@ -164,6 +164,60 @@ def synthetic_vae_decoder(cfg: EngineConfig, seed=0):
     return b.sd
 
 
+def synthetic_vae_encoder(cfg: EngineConfig, seed=0):
+    """AutoencoderKL encoder + quant_conv keys (the half of vae/ used by dataloader.py:808)."""
+    v = cfg.vae
+    b = _Builder("vae.", seed)
+    ch = v.block_out_channels
+    b.conv("encoder.conv_in", ch[0], v.out_channels, 3)
+
+    def resnet(p, cin, cout):
+        b.norm(p + ".norm1", cin)
+        b.conv(p + ".conv1", cout, cin, 3)
+        b.norm(p + ".norm2", cout)
+        b.conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            b.conv(p + ".conv_shortcut", cout, cin, 1)
+
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(v.layers_per_block):
+            resnet("encoder.down_blocks.%d.resnets.%d" % (i, j), prev if j == 0 else c, c)
+        prev = c
+        if i < len(ch) - 1:
+            b.conv("encoder.down_blocks.%d.downsamplers.0.conv" % i, c, c, 3)
+    top = ch[-1]
+    resnet("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    b.norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        b.linear(a + "." + n, top, top)
+    resnet("encoder.mid_block.resnets.1", top, top)
+    b.norm("encoder.conv_norm_out", top)
+    b.conv("encoder.conv_out", 2 * v.latent_channels, top, 3)
+    b.conv("quant_conv", 2 * v.latent_channels, 2 * v.latent_channels, 1)
+    return b.sd
+
+
+def synthetic_text_encoder(cfg: EngineConfig, seed=0):
+    """transformers CLIPTextModel state-dict keys (text_encoder/ of the SD-1.x repo)."""
+    t = cfg.text
+    b = _Builder("text.", seed)
+    tm = "text_model."
+    b.sd[tm + "embeddings.token_embedding.weight"] = _randn("text.tok", (t.vocab_size, t.hidden_size), 0.5, seed)
+    b.sd[tm + "embeddings.position_embedding.weight"] = _randn("text.pos", (t.max_position_embeddings, t.hidden_size), 0.5, seed)
+    for l in range(t.num_hidden_layers):
+        p = tm + "encoder.layers.%d" % l
+        b.norm(p + ".layer_norm1", t.hidden_size)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            b.linear(p + ".self_attn." + n, t.hidden_size, t.hidden_size)
+        b.norm(p + ".layer_norm2", t.hidden_size)
+        b.linear(p + ".mlp.fc1", t.intermediate_size, t.hidden_size)
+        b.linear(p + ".mlp.fc2", t.hidden_size, t.intermediate_size)
+    b.norm(tm + "final_layer_norm", t.hidden_size)
+    return b.sd
+
+
 def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
     g = cfg.guide
     b = _Builder("guide.", seed)
@@ -188,9 +242,14 @@ def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
     return b.sd
 
 
-def synthetic_weights(cfg: EngineConfig, seed=0, num_classes=100):
-    return {"unet": synthetic_unet(cfg, seed), "vae": synthetic_vae_decoder(cfg, seed),
-            "guide": synthetic_guide(cfg, seed, num_classes)}
+def synthetic_weights(cfg: EngineConfig, seed=0, num_classes=100, encoders=False):
+    """encoders=True adds the stage before the loop (VAE encoder + CLIP text encoder)."""
+    w = {"unet": synthetic_unet(cfg, seed), "vae": synthetic_vae_decoder(cfg, seed),
+         "guide": synthetic_guide(cfg, seed, num_classes)}
+    if encoders:
+        w["vae"].update(synthetic_vae_encoder(cfg, seed))
+        w["text"] = synthetic_text_encoder(cfg, seed)
+    return w
 
 
 def load_safetensors_dir(model_dir, sub, names=("diffusion_pytorch_model.safetensors",)):

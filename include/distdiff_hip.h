@@ -19,6 +19,8 @@
  *   dd_decode              vae.decode + image_processor.postprocess             generate_data.py:1221-1228
  *   dd_expand              the per-(batch, expand index) denoise loop           generate_data.py:1161-1228
  *   dd_guide_encode        image_encoder.encode_image                           model_utils.py:29-41
+ *   dd_vae_encode          vae.encode(x).latent_dist.sample() * scaling_factor  dataloader.py:808-809   (stage before the loop, 8f-2)
+ *   dd_text_encode         text_encoder(input_ids)[0]                           dataloader.py:633-646   (stage before the loop, 8f-2)
  *
  * Ownership: every tensor argument is caller-owned DEVICE memory unless marked host; the engine borrows it for
  * the duration of the enqueued work. The engine owns packed weights and its activation workspace.
@@ -64,6 +66,10 @@ typedef struct dd_config {
   int latent_size, text_len, max_batch;
   int enable_grad;      /* 1: build the VJP programs and stash activations (energy guidance) */
   int max_guidance_period; /* P: chained guided steps kept alive for transform_guidance */
+  /* CLIPTextModel (text_encoder/config.json); vocabulary, width, depth and MLP size are taken from the state dict */
+  int text_heads;       /* num_attention_heads (0: 12) */
+  int text_act;         /* hidden_act: 0 quick_gelu (SD-1.x), 1 gelu */
+  float text_eps;       /* layer_norm_eps (0: 1e-5) */
 } dd_config;
 
 typedef struct dd_sampler_params {
@@ -94,7 +100,7 @@ int dd_create(const dd_config* cfg, dd_engine** out);
 void dd_destroy(dd_engine* e);
 const char* dd_last_error(dd_engine* e);
 
-/* model: "unet" | "vae" | "guide"; key: Hugging Face / timm state-dict key; data: HOST fp32 */
+/* model: "unet" | "vae" | "guide" | "text"; key: Hugging Face / timm state-dict key; data: HOST fp32 */
 int dd_load_tensor(dd_engine* e, const char* model, const char* key, const float* data, int ndim, const int64_t* shape);
 int dd_finalize_weights(dd_engine* e);
 
@@ -119,6 +125,14 @@ int dd_expand(dd_engine* e, const dd_expand_args* a, void* stream);
 int dd_image_to_u8(dd_engine* e, const float* image, uint8_t* out_hwc, int B, void* stream);
 /* images: DEVICE fp32 [B,3,S,S] (S = guide_input_size) -> feats DEVICE fp32 [B, D] */
 int dd_guide_encode(dd_engine* e, const float* images, float* feats, int B, void* stream);
+/* The stage before the loop; available when the state dicts carried vae/encoder.* + quant_conv.* and
+ * text/text_model.* keys.  images: DEVICE fp32 [B,3,8L,8L] in [-1,1]; noise: DEVICE fp32 [B,4,L,L] ~ N(0,1) or NULL (the
+ * distribution's mode); latents_out [B,4,L,L] already multiplied by scaling_factor; moments_out optional [B,8,L,L]
+ * (mean | logvar clamped to [-30,20]). */
+int dd_vae_encode(dd_engine* e, const float* images, const float* noise, float* latents_out, float* moments_out, int B, void* stream);
+/* input_ids: DEVICE int32 [n, text_len] (tokenizer output, padded to text_len); embeds_out DEVICE fp32 [n, text_len, cross_dim]
+ * = last_hidden_state after final_layer_norm; 1 <= n <= 2*max_batch */
+int dd_text_encode(dd_engine* e, const int* input_ids, float* embeds_out, int n, void* stream);
 /* diagnostic: raw UNet forward, eps2_out DEVICE fp32 [2B,4,L,L] (uncond half first) */
 int dd_unet_forward(dd_engine* e, const float* z, int step_index, float* eps2_out, int B, void* stream);
 

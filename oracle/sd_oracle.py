@@ -22,6 +22,8 @@ Reference lines restated (file:line in /root/reference):
   main denoise loop       generate_data.py:1161-1228
   encode_image            model_utils.py:29-41   (forward_features -> AdaptiveAvgPool2d(1) -> flatten)
   shard ranges            generate_data.py:1003-1007
+  (8f-2) vae.encode / text_encoder(input_ids)[0]   dataloader.py:808-809, 633-646 -> vae_encode, clip_text_encode; the
+          latter IS pinned: transformers (importable here) runs its own CLIPTextModel in tests/golden/make_clip_fixture.py.
 """
 import math
 
@@ -224,6 +226,64 @@ class VAEOracle:
         h = F.silu(F.group_norm(h, g, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps))
         h = F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
         return (h,)
+
+
+def vae_encode(cfg, sd, images, noise=None):
+    """AutoencoderKL.encode(x).latent_dist.sample() * scaling_factor (dataloader.py:808-809), restated from the
+    published diffusers-0.28 Encoder: conv_in; DownEncoderBlock2D x levels (resnets, then F.pad(0,1,0,1) + stride-2 3x3 conv);
+    mid Res-Attn-Res; GN+SiLU+conv_out; quant_conv; DiagonalGaussianDistribution (logvar clamped to [-30, 20]).
+    Returns (latents, moments[mean | clamped logvar]); noise=None gives the mode."""
+    v = cfg.vae
+    g, eps = v.norm_num_groups, v.norm_eps
+    h = F.conv2d(images, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    nlev = len(v.block_out_channels)
+    for i in range(nlev):
+        for j in range(v.layers_per_block):
+            h = _resnet(sd, "encoder.down_blocks.%d.resnets.%d" % (i, j), h, None, g, eps)
+        if i < nlev - 1:
+            p = "encoder.down_blocks.%d.downsamplers.0.conv" % i
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+    h = _resnet(sd, "encoder.mid_block.resnets.0", h, None, g, eps)
+    a = "encoder.mid_block.attentions.0"
+    B, Cc, H, W = h.shape
+    n = F.group_norm(h, g, sd[a + ".group_norm.weight"], sd[a + ".group_norm.bias"], eps)
+    n = n.reshape(B, Cc, H * W).transpose(1, 2)
+    h = h + _attention(sd, a, n, n, 1).transpose(1, 2).reshape(B, Cc, H, W)
+    h = _resnet(sd, "encoder.mid_block.resnets.1", h, None, g, eps)
+    h = F.silu(F.group_norm(h, g, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], eps))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    m = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    mean, logvar = m.chunk(2, dim=1)
+    logvar = logvar.clamp(-30.0, 20.0)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    return z * v.scaling_factor, torch.cat([mean, logvar], 1)
+
+
+def clip_text_encode(cfg, sd, input_ids):
+    """transformers CLIPTextModel(input_ids)[0] (dataloader.py:633-646): token + position embeddings, pre-LN layers with
+    causal self-attention and quick_gelu / gelu MLP, final LayerNorm.  Pinned against transformers' own CLIPTextModel by
+    tests/golden/make_clip_fixture.py (transformers is importable in the build container)."""
+    t = cfg.text
+    tm = "text_model."
+    ids = input_ids.long()
+    B, T = ids.shape
+    x = sd[tm + "embeddings.token_embedding.weight"][ids] + sd[tm + "embeddings.position_embedding.weight"][:T][None]
+    heads = t.num_attention_heads
+    d = t.hidden_size // heads
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    for l in range(t.num_hidden_layers):
+        p = tm + "encoder.layers.%d" % l
+        h = F.layer_norm(x, (t.hidden_size,), sd[p + ".layer_norm1.weight"], sd[p + ".layer_norm1.bias"], t.layer_norm_eps)
+        q, k, v = (F.linear(h, sd[p + ".self_attn.%s.weight" % n], sd[p + ".self_attn.%s.bias" % n]).reshape(B, T, heads, d).transpose(1, 2)
+                   for n in ("q_proj", "k_proj", "v_proj"))
+        w = (q @ k.transpose(-1, -2)) * d ** -0.5 + mask
+        o = (w.softmax(-1) @ v).transpose(1, 2).reshape(B, T, t.hidden_size)
+        x = x + F.linear(o, sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (t.hidden_size,), sd[p + ".layer_norm2.weight"], sd[p + ".layer_norm2.bias"], t.layer_norm_eps)
+        h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
+        h = h * torch.sigmoid(1.702 * h) if t.hidden_act == "quick_gelu" else F.gelu(h)
+        x = x + F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    return F.layer_norm(x, (t.hidden_size,), sd[tm + "final_layer_norm.weight"], sd[tm + "final_layer_norm.bias"], t.layer_norm_eps)
 
 
 class ImageProcessorOracle:

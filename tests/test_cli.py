@@ -98,3 +98,27 @@ def test_prototype_builder_known_answer():
         got = sorted(map(tuple, np.round(l[c] / (c + 1) / 5).astype(int).tolist()))
         assert got == [(0, 0, 1), (0, 1, 0), (1, 0, 0)]
         assert np.allclose(g[c], feats[np.array(tg) == c].mean(0))
+
+
+def test_image_transform_matches_reference_pipeline(tmp_path):
+    """Resize(size, BILINEAR) -> CenterCrop(size) -> ToTensor -> Normalize([0.5],[0.5]) (dataloader.py:758-765)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distdiff_amd.preprocess import CUSTOM_TEMPLATES, load_image, resize_crop_size
+    assert resize_crop_size(300, 200, 64) == (96, 64) and resize_crop_size(200, 300, 64) == (64, 96) and resize_crop_size(50, 50, 64) == (64, 64)
+    rng = np.random.RandomState(1)
+    p = str(tmp_path / "a.png")
+    Image.fromarray(rng.randint(0, 255, (90, 150, 3), dtype=np.uint8)).save(p)
+    x = load_image(p, 64, center_crop=True)
+    assert x.shape == (3, 64, 64) and x.dtype == torch.float32 and float(x.min()) >= -1.0 and float(x.max()) <= 1.0
+    # restated by hand: the smaller edge (90) becomes 64, the width int(64 * 150 / 90) = 106, centre crop offset round((106-64)/2) = 21
+    ref = Image.open(p).resize((106, 64), Image.BILINEAR).crop((21, 0, 85, 64))
+    ref = torch.from_numpy(np.asarray(ref).copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1
+    assert torch.equal(x, ref)
+    # grey-scale files are converted to RGB (dataloader.py:805-806); random crop stays inside the image and is seedable
+    Image.fromarray(rng.randint(0, 255, (70, 70), dtype=np.uint8)).save(str(tmp_path / "g.png"))
+    g1 = load_image(str(tmp_path / "g.png"), 64, rng=np.random.RandomState(3))
+    g2 = load_image(str(tmp_path / "g.png"), 64, rng=np.random.RandomState(3))
+    assert g1.shape == (3, 64, 64) and torch.equal(g1, g2) and torch.equal(g1[0], g1[1])
+    assert CUSTOM_TEMPLATES["caltech-101"].format("sea horse") == "a photo of a sea horse."

@@ -32,3 +32,50 @@ def test_cli_writes_png_tree_and_resumes(hip_lib, tmp_path, capsys):
     out2 = _run(tmp_path, 1, 2)                # the other shard adds the remaining images, no overlap
     files2 = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out2) for f in fs)
     assert len(files2) == 12
+
+
+def test_cli_synthetic_encode_runs_both_encoders(hip_lib, tmp_path):
+    """--synthetic_encode: latents from the HIP VAE encoder, prompt embeddings from the HIP text encoder, then the same loop."""
+    out = _run(tmp_path, 0, 1, extra=["--synthetic_encode"])
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
+    assert len(files) == 12
+
+
+def test_latent_cache_format_and_reuse(hip_lib, tmp_path):
+    """dataloader.py:788-811: images on disk -> list of [1,4,L,L] latents saved to image_latents.pt; a second call loads the file."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.preprocess import load_image, load_or_encode_latents
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    cfg = tiny_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=2, encoders=True)
+    rng = np.random.RandomState(0)
+    paths = []
+    for i, (wd, ht) in enumerate([(160, 200), (300, 140), (128, 128)]):     # portrait, landscape, exact
+        p = str(tmp_path / ("img%d.png" % i))
+        Image.fromarray(rng.randint(0, 255, (ht, wd, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    size = 8 * cfg.latent_size
+    eng = Engine(cfg, w, enable_grad=False, max_guidance_period=1)
+    try:
+        root = str(tmp_path / "save")
+        lat = load_or_encode_latents(eng, "toy", "org/model", paths, size, center_crop=True, seed=5, root=root)
+        f = os.path.join(root, "toy", "org--model", "image_latents.pt")
+        assert os.path.exists(f)
+        assert len(lat) == 3 and all(tuple(x.shape) == (1, 4, cfg.latent_size, cfg.latent_size) for x in lat)
+        again = load_or_encode_latents(eng, "toy", "org/model", ["/nonexistent.png"], size, root=root)   # served from the cache
+        assert all(torch.equal(a, b) for a, b in zip(lat, again))
+        # against the oracle on the same preprocessed pixels and the same seeded noise stream (3 images = batches of 2 + 1)
+        g = torch.Generator().manual_seed(5)
+        x = torch.stack([load_image(p, size, True) for p in paths])
+        n = torch.cat([torch.randn(2, 4, cfg.latent_size, cfg.latent_size, generator=g), torch.randn(1, 4, cfg.latent_size, cfg.latent_size, generator=g)])
+        with torch.no_grad():
+            ref, _ = O.vae_encode(cfg, w["vae"], x, n)
+        got = torch.cat(lat)
+        assert ((got - ref).norm() / ref.norm()).item() < 0.03
+    finally:
+        eng.close()

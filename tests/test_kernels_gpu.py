@@ -232,6 +232,25 @@ def test_attention(ops, case):
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
 
 
+@pytest.mark.parametrize("case", [("clip_causal_77_d64", 3, 12, 77, 77, 64), ("causal_130_d64", 2, 2, 130, 130, 64)], ids=lambda c: c[0])
+def test_attention_causal(ops, case):
+    """causal forward (CLIP text encoder: key j visible to query i iff j <= i)."""
+    name, B, H, Nq, Nk, D = case
+    g = torch.Generator().manual_seed(17)
+    q = bf(torch.randn(B, Nq, H, D, generator=g))
+    k = bf(torch.randn(B, Nk, H, D, generator=g))
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    scale = 1.0 / math.sqrt(D)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    s = s.masked_fill(torch.ones(Nq, Nk).triu(1).bool(), float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    o, lse = ops.attention(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale, causal=True)
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref, rtol=2e-2, atol=2e-3, what=name + " O")
+    assert_close(lse, torch.logsumexp(s, dim=-1), rtol=1e-3, atol=1e-3, what=name + " LSE")
+
+
 def test_elementwise_sampler_ops(ops):
     from distdiff_amd import _lib
     L = _lib.lib()

@@ -153,3 +153,48 @@ def test_primitives_against_torch_functional(models):
     ref = sum((f[i] - Pc[y[i]]).norm() for i in range(3)) / 3
     ref = ref + 0.5 * sum((f[i] - Pg[y[i], int((Pg[y[i]] @ f[i]).argmax())]).norm() for i in range(3)) / 3
     assert abs(float(e) - float(ref)) < 1e-5
+
+
+def test_clip_text_oracle_matches_transformers_fixture():
+    """oracle clip_text_encode vs the vectors recorded from transformers' own CLIPTextModel (tests/golden/make_clip_fixture.py)."""
+    import os
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.weights import synthetic_text_encoder
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "clip_fixture.pt"), weights_only=False)
+    assert len(fx["cases"]) == 2
+    for c in fx["cases"]:
+        cfg = tiny_config()
+        cfg.text.hidden_act = c["hidden_act"]
+        out = O.clip_text_encode(cfg, synthetic_text_encoder(cfg, 0), c["input_ids"])
+        assert (out - c["last_hidden_state"]).abs().max().item() < 1e-4
+        # causality: changing a later token never changes an earlier position
+        ids2 = c["input_ids"].clone()
+        ids2[:, 7] = (ids2[:, 7] + 1) % cfg.text.vocab_size
+        out2 = O.clip_text_encode(cfg, synthetic_text_encoder(cfg, 0), ids2)
+        assert torch.equal(out2[:, :7], out[:, :7]) and not torch.equal(out2[:, 7:], out[:, 7:])
+
+
+def test_vae_encode_oracle_primitives():
+    """the encoder downsample is F.pad(0,1,0,1) + stride-2 conv; the sample is mean + exp(logvar/2) * noise, times scaling_factor."""
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.weights import synthetic_vae_decoder, synthetic_vae_encoder
+    cfg = tiny_config()
+    sd = synthetic_vae_decoder(cfg, 0)
+    sd.update(synthetic_vae_encoder(cfg, 0))
+    g = torch.Generator().manual_seed(3)
+    S = 8 * cfg.latent_size
+    x = torch.rand(2, 3, S, S, generator=g) * 2 - 1
+    n = torch.randn(2, 4, cfg.latent_size, cfg.latent_size, generator=g)
+    with torch.no_grad():
+        z, mom = O.vae_encode(cfg, sd, x, n)
+        zm, mom2 = O.vae_encode(cfg, sd, x, None)
+    assert z.shape == (2, 4, cfg.latent_size, cfg.latent_size) and mom.shape == (2, 8, cfg.latent_size, cfg.latent_size)
+    assert torch.equal(mom, mom2)
+    assert torch.allclose(zm, mom[:, :4] * cfg.vae.scaling_factor)
+    assert torch.allclose(z, (mom[:, :4] + torch.exp(0.5 * mom[:, 4:]) * n) * cfg.vae.scaling_factor)
+    assert float(mom[:, 4:].min()) >= -30.0 and float(mom[:, 4:].max()) <= 20.0
+    # asymmetric padding: the last output row/column sees one zero row/column, the first sees none
+    w = torch.randn(5, 3, 3, 3, generator=g)
+    a = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
+    b = F.conv2d(F.pad(x, (1, 1, 1, 1)), w, stride=2)
+    assert a.shape[-1] == S // 2 and not torch.allclose(a, b[..., : S // 2, : S // 2])
