@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libdistdiff_hip.so")
 SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "norm.hip", "attention.hip", "elementwise.hip", "weights.cpp", "ops_abi.cpp", "engine.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3"] + (["-DDD_STAMPS"] if os.environ.get("DD_STAMPS") else []) + ["-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
+FLAGS = ["--offload-arch=gfx950", "-O3"] + os.environ.get("DD_EXTRA_CFLAGS", "").split() + ["-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
          "-I", os.path.join(HERE, "..", "include")]
 
 

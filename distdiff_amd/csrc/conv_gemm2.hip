@@ -17,6 +17,16 @@ namespace {
 
 __device__ uint4 g_zero16[4];   // zero page for padded taps / ragged rows (device globals are zero-initialised)
 
+// One 1 KB LDS-DMA piece: buffer_load_dwordx4 ... lds from base + voff (per lane) + soff (scalar); a lane whose voff is beyond the
+// 4 GB - 256 B range gets zeros written to its LDS slot (hardware range check) -- that is how padding taps and ragged rows are
+// staged.  The resource builtins only exist in the device pass (a kernel template that names them loses its host stub otherwise).
+__device__ __forceinline__ void dma16(const void* base, void* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffff00u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
 // FM: 1 = scalar-tap fast path compiled in, 0 = general path only, 2 = chosen at run time. The compile-time forms help the
 // shallow-K (FE) instantiation by 5-6 %, the run-time form is 1-6 % faster on deep-K shapes (same-device A/B): compiler scheduling.
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
@@ -75,10 +85,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   int* taps = (int*)(smem + NS * BUF_BYTES);
   for (int t = tid; t < p.ntaps; t += NT) taps[t] = p.taptab[t];
   __syncthreads();
+  // Fast path staging uses buffer_load ... lds: the per-lane byte offset of a row is fixed for a whole work item, the K-step
+  // (tap, 64-channel chunk) moves through the scalar offset, and an out-of-range offset makes the hardware write zeros
+  // (padding taps, ragged rows) -- 3 VALU per 1 KB piece instead of a 64-bit address select.  The base is moved back by the most
+  // negative tap offset so that the scalar offset stays unsigned.
+  constexpr unsigned OOB = 0xfffffff0u;
+  int tap_bias = 0;
+  if (fast) {
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int e = taps[t];
+      tap_bias = max(tap_bias, -((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld * 2);
+    }
+    tap_bias = __builtin_amdgcn_readfirstlane(tap_bias);
+    __syncthreads();
+    for (int t = tid; t < p.ntaps; t += NT) {
+      const int e = taps[t];
+      taps[32 + t] = tap_bias + ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld * 2;
+    }
+    __syncthreads();
+  }
+  const char* xbase = (const char*)p.x - tap_bias;
   int lw = w_first, l_kt = 0, l_kend = 0;
+  int l_tap = 0, l_chunk = 0, l_tb = 0;       // fast path: tap / chunk of K-step l_kt and its (prefetched) byte offset
   int pixb[AV], iy0[AV], ix0[AV];             // general path
   unsigned tapmask[AV];                       // fast path: bit t = tap t is inside the image for this row
   unsigned wrow[BV];                          // element offset of this lane's weight row (+ K-slot), or ~0u
+  // Output-column layout of a wave's TN 16-wide MFMA tiles.  Tiles are paired (2t, 2t+1): LDS weight row (jn, f) of a pair holds
+  // channel t*32 + (f>>2)*8 + (jn&1)*4 + (f&3), so a lane's 4+4 accumulator rows of the pair are 8 CONSECUTIVE output channels and
+  // the epilogue moves 16 bytes per lane (4 lanes = 64 contiguous bytes per pixel) instead of 8.  An odd last tile keeps the plain
+  // layout; GEGLU has its own (hidden | gate) pairing.  The permutation costs nothing: it only changes which weight row a DMA
+  // lane fetches.
+  const bool pair_cols = !(p.flags & CF_GEGLU);
+  constexpr int TNP = TN & ~1;
+  auto chan_of_row = [&](int R) {
+    const int wv = R / (TN * 16), q = R - wv * (TN * 16);
+    const int jn = q >> 4, f = q & 15;
+    return (pair_cols && jn < TNP) ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
+  };
+  auto col_of = [&](int jn) {   // first of the 4 consecutive columns this lane holds of tile jn, relative to the wave's span
+    return (pair_cols && jn < TNP) ? (jn >> 1) * 32 + fq * 8 + (jn & 1) * 4 : jn * 16 + fq * 4;
+  };
   auto setup_loader = [&](int w) {
     const int kz = w % p.ksplit, tile = w / p.ksplit;
     const int m0 = (tile / ntn) * BM;
@@ -98,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
         y0 = oy * p.stride;
         x0 = ox * p.stride;
         if (fast) {
-          pb = ((b * p.H + y0) * p.W + x0) * p.x_ld;     // element offset of the centre pixel
+          pb = ((b * p.H + y0) * p.W + x0) * p.x_ld * 2 + j * 16;     // byte offset of the centre pixel + this lane's K-slot
           for (int t = 0; t < p.ntaps; ++t) {
             const int e = taps[t];
             const int yy = y0 + ((e >> 6) & 63) - 32, xx = x0 + (e & 63) - 32;
@@ -113,25 +159,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
       const bool half = B_HALF && i == BV - 1;
-      const int n = n0 + RPT * i + (half ? rh : r0);
-      wrow[i] = n < p.N ? (unsigned)n * (unsigned)p.K + (unsigned)((half ? jh : j) * 8) : 0xffffffffu;
+      const int n = n0 + chan_of_row(RPT * i + (half ? rh : r0));
+      wrow[i] = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)((half ? jh : j) * 8)) * 2u : OOB;   // bytes
+    }
+    if (fast) {
+      l_chunk = l_kt / p.ntaps;
+      l_tap = l_kt - l_chunk * p.ntaps;
     }
   };
+  // byte offset of the loader's tap, read one K-step before issue_step consumes it (unconditional: see the note on the peeled step)
+  auto prefetch_tap = [&]() { if (fast) l_tb = taps[32 + l_tap]; };
   auto issue_step = [&](int buf) {   // enqueue the LDS-DMA of K-step l_kt of the loader's item into buffer `buf`
     const int kt = l_kt;
+
     unsigned char* Abase = smem + buf * BUF_BYTES + wave * 1024;
     unsigned char* Bbase = smem + buf * BUF_BYTES + BM * 128 + wave * 1024;
     if (fast) {
-      const int chunk = kt / p.ntaps;                        // wave-uniform; K order = (64-channel chunk, tap)
-      const int tap = kt - chunk * p.ntaps;
-      const int e = taps[tap];
-      const int tapoff = ((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld + chunk * 64 + j * 8;
+      // K order = (64-channel chunk, tap): wave-uniform scalar offset, per-lane offsets fixed since setup_loader
+      const unsigned soff = (unsigned)(__builtin_amdgcn_readfirstlane(l_tb) + l_chunk * 128);
 #pragma unroll
       for (int i = 0; i < AV; ++i) {
-        const bool ok = (tapmask[i] >> tap) & 1u;
-        const bf16_t* src = ok ? p.x + (unsigned)(pixb[i] + tapoff) : (const bf16_t*)g_zero16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Abase + i * (RPT * 128)), 16, 0, 0);
+        const unsigned voff = ((tapmask[i] >> l_tap) & 1u) ? (unsigned)pixb[i] : OOB;
+        dma16(xbase, Abase + i * (RPT * 128), voff, soff);
       }
     } else {
       int e, coff;
@@ -161,24 +210,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
                                          (__attribute__((address_space(3))) void*)(Abase + i * (RPT * 128)), 16, 0, 0);
       }
     }
+    const unsigned wsoff = (unsigned)kt * 128u;
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      const bf16_t* src = wrow[i] != 0xffffffffu ? p.w + ((size_t)wrow[i] + (size_t)kt * 64) : (const bf16_t*)g_zero16;
       if (B_HALF && i == BV - 1) {
         // half pass: every wave moves 4 rows with its lanes 0-31 (same DMA count in every wave, so counted vmcnt waits are uniform)
         if (lane < 32)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(smem + buf * BUF_BYTES + BM * 128 + i * (RPT * 128) + wave * 512),
-                                           16, 0, 0);
+          dma16(p.w, smem + buf * BUF_BYTES + BM * 128 + i * (RPT * 128) + wave * 512, wrow[i], wsoff);
       } else {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Bbase + i * (RPT * 128)), 16, 0, 0);
+        dma16(p.w, Bbase + i * (RPT * 128), wrow[i], wsoff);
       }
     }
   };
   // advance the loader to the next K-step; returns false when the work list is exhausted
   auto advance_loader = [&]() -> bool {
-    if (++l_kt < l_kend) return true;
+    if (++l_kt < l_kend) {
+      if (fast && ++l_tap == p.ntaps) { l_tap = 0; ++l_chunk; }
+      return true;
+    }
     lw += Gx;
     if (lw >= w_end) return false;
     setup_loader(lw);
@@ -192,29 +241,40 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto compute = [&](int buf) {
+  // fragments of one 32-wide K half of a stage: TN weight rows + TM pixel rows per lane (ds_read_b128 each)
+  struct Frags { bf16x8 wf[TN]; bf16x8 xf[TM]; };
+  auto load_frags = [&](Frags& F, int buf, int ks) {
     const unsigned char* A = smem + buf * BUF_BYTES;
     const unsigned char* Bt = A + BM * 128;
+    const int slot = fq + 4 * ks;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = fq + 4 * ks;
-      bf16x8 wf[TN];
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int row = wn * (TN * 16) + jn * 16 + fr;
-        wf[jn] = *(const bf16x8*)(Bt + row * 128 + ((slot ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 16) + i * 16 + fr;
-        const bf16x8 xf = *(const bf16x8*)(A + row * 128 + ((slot ^ (row & 7)) << 4));
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf, acc[jn][i], 0, 0, 0);
-      }
+    for (int jn = 0; jn < TN; ++jn) {
+      const int row = wn * (TN * 16) + jn * 16 + fr;
+      F.wf[jn] = *(const bf16x8*)(Bt + row * 128 + ((slot ^ (row & 7)) << 4));
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (TM * 16) + i * 16 + fr;
+      F.xf[i] = *(const bf16x8*)(A + row * 128 + ((slot ^ (row & 7)) << 4));
+    }
+  };
+  auto mma = [&](const Frags& F) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.wf[jn], F.xf[i], acc[jn][i], 0, 0, 0);
   };
   const float* bias = p.bias;
   if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  // bias of the item's columns, fetched when the item STARTS (right after the previous item's stores, where the pipeline waits with
+  // vmcnt(0) anyway) so that the epilogue begins without a dependent global load
+  float4 bv[TN];
+  auto prefetch_bias = [&](int w) {
+    const int n0 = ((w / p.ksplit) % ntn) * BN;
+    const bool ok = (p.flags & CF_BIAS) && p.ksplit == 1 && pair_cols && (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.N & 7);
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) bv[jn] = ok ? *(const float4*)(bias + n0 + wn * (TN * 16) + col_of(jn)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
   auto epilogue = [&](int w) {
     const int kz = w % p.ksplit, tile = w / p.ksplit;
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -226,7 +286,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
         if (m >= p.M) continue;
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-          const int nb = n0 + wn * (TN * 16) + jn * 16 + fq * 4;
+          const int nb = n0 + wn * (TN * 16) + col_of(jn);
           float* pp = part + (size_t)m * p.N + nb;
           if (nb + 4 <= p.N && !(p.N & 3)) {
             *(float4*)pp = make_float4(acc[jn][i][0], acc[jn][i][1], acc[jn][i][2], acc[jn][i][3]);
@@ -243,35 +303,45 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
     // epilogue pays one memory latency per row instead of one per 4-column group
     if constexpr (FE) {
     const int ncol0 = n0 + wn * (TN * 16) + fq * 4;
-    const bool tile_full = (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.y_ld & 3) && !(p.N & 3);
+    const bool tile_full = (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.y_ld & 7) && !(p.N & 7);
     const int fl = p.flags;
-    if (tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 3))) {
-      float4 bv[TN];
+    if (tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
+      // bias was prefetched into bv[] when the item started (prefetch_bias); 16-byte loads / stores per tile pair
+      const int wb = n0 + wn * (TN * 16);
+      const int cp = wb + fq * 8, co = wb + (TN - 1) * 16 + fq * 4;       // pair t: cp + 32 t ; odd last tile: co
+      uint4 rvp[TM][TN / 2];
+      uint2 rvo[TM];
+      if (fl & CF_RES) {
 #pragma unroll
-      for (int jn = 0; jn < TN; ++jn) bv[jn] = (fl & CF_BIAS) ? *(const float4*)(bias + ncol0 + jn * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < TM; ++i) {
+          const int m = min(m0 + wm * (TM * 16) + i * 16 + fr, p.M - 1);
+          const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
+#pragma unroll
+          for (int t = 0; t < TN / 2; ++t) rvp[i][t] = *(const uint4*)(rp + cp + 32 * t);
+          if constexpr (TN & 1) rvo[i] = *(const uint2*)(rp + co);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (m >= p.M) continue;
-        uint2 rv[TN];
-        if (fl & CF_RES) {
-          const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld + ncol0;
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn) rv[jn] = *(const uint2*)(rp + jn * 16);
-        }
-        bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld + ncol0;
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-          float v0 = acc[jn][i][0] * p.alpha + bv[jn].x, v1 = acc[jn][i][1] * p.alpha + bv[jn].y;
-          float v2 = acc[jn][i][2] * p.alpha + bv[jn].z, v3 = acc[jn][i][3] * p.alpha + bv[jn].w;
+        bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
+        auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1) {
+          float v0 = a[0] * p.alpha + b.x, v1 = a[1] * p.alpha + b.y, v2 = a[2] * p.alpha + b.z, v3 = a[3] * p.alpha + b.w;
           if (fl & CF_RES) {
-            v0 += __uint_as_float(rv[jn].x << 16); v1 += __uint_as_float(rv[jn].x & 0xffff0000u);
-            v2 += __uint_as_float(rv[jn].y << 16); v3 += __uint_as_float(rv[jn].y & 0xffff0000u);
+            v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
+            v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
           }
           if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-          uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
-          *(uint2*)(yp + jn * 16) = o;
+          return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        };
+#pragma unroll
+        for (int t = 0; t < TN / 2; ++t) {
+          const uint2 lo = four(acc[2 * t][i], bv[2 * t], rvp[i][t].x, rvp[i][t].y);
+          const uint2 hi = four(acc[2 * t + 1][i], bv[2 * t + 1], rvp[i][t].z, rvp[i][t].w);
+          *(uint4*)(yp + cp + 32 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
+        if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y);
       }
       return;
     }
@@ -328,7 +398,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
       } else {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-          const int nb = n0 + wn * (TN * 16) + jn * 16 + fq * 4;
+          const int nb = n0 + wn * (TN * 16) + col_of(jn);
           if (nb >= p.N) continue;
           float h[4];
 #pragma unroll
@@ -339,57 +409,87 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
     }
   };
 
-  // ---- pipeline: NS = 3 LDS stages, the loader runs two K-steps ahead of the compute iterator, across work items.
-  // A stage is read one barrier after the counted s_waitcnt that retires its DMA and re-filled one barrier after its last
-  // read. vmcnt counts every VMEM op of the wave in issue order, so after an epilogue (whose loads/stores interleave with
-  // the DMAs) the iteration drains with vmcnt(0) instead of the counted wait.
+  // ---- pipeline: NS = 3 LDS stages, software-pipelined through registers.  K-step s reads its two 32-wide halves as
+  // fragment sets F0 / F1:
+  //     ds_read F1(s)            | hidden by
+  //     MFMA    F0(s)            |
+  //     s_waitcnt vmcnt ; s_barrier     -> stage s+1 has landed for every wave; every wave has issued all reads of stage s
+  //     ds_read F0(s+1)          | hidden by
+  //     DMA     step s+3 -> the stage of step s (waves 0-3 before, waves 4-7 after the MFMAs: SIMD partners alternate)
+  //     MFMA    F1(s)            |
+  // so no LDS latency is exposed to the MFMA stream, the stage of step s is re-filled as soon as its reads are issued (the loader
+  // runs three K-steps ahead, across work items) and there is one barrier per K-step.  vmcnt counts every VMEM op of the wave in
+  // issue order, so after an epilogue (whose loads/stores interleave with the DMAs) the next wait drains with vmcnt(0).
+  static_assert(NS == 3, "three stages");
   auto wait_dma = [&](bool keep_one_stage) {
-    if (NS == 3 && keep_one_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    if (keep_one_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  setup_loader(lw);
-  issue_step(0);
-  bool more = advance_loader();
-  bool issued = false;
-  if (NS == 3 && more) { issue_step(1); more = advance_loader(); issued = true; }
-  wait_dma(issued);
   int cw = w_first;                                   // compute iterator
   int c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
+  int total_steps = 0;                                // K-steps of this workgroup's whole work list
+  for (int w = w_first; w < w_end; w += Gx) total_steps += min(ksteps, (w % p.ksplit) * per + per) - (w % p.ksplit) * per;
+  prefetch_bias(w_first);
+  setup_loader(lw);
+  prefetch_tap();
+  issue_step(0);
+  bool more = advance_loader();
+  prefetch_tap();
+  int ahead = 0;                                      // DMA stages in flight (after the first wait: including the one needed next)
+  if (more) { issue_step(1); more = advance_loader(); prefetch_tap(); ahead = 1; }
+  wait_dma(ahead == 1);
+  if (more) { issue_step(2); more = advance_loader(); prefetch_tap(); ahead = 2; }
   zero_acc();
-  int cur = 0, fill = NS - 1;                         // stage being computed / stage the next DMA goes to
-  while (true) {
-    issued = false;
-    const bool issue_first = (NW == 8) ? (wave < 4) : true;   // SIMD partners run DMA issue and MFMAs in opposite order
-    const bool had_more = more;
-    const int fill_now = fill;
-    if (had_more) { issued = true; fill = fill == NS - 1 ? 0 : fill + 1; }
-    if (had_more && issue_first) issue_step(fill_now);
-    compute(cur);
-    if (had_more && !issue_first) issue_step(fill_now);
-    if (had_more) more = advance_loader();
-    bool done = false, drained = false;
+  Frags F0, F1;
+  load_frags(F0, 0, 0);
+  const bool issue_first = wave < 4;                  // SIMD partners run DMA issue and MFMAs in opposite order
+  int cur = 0;
+  bool drained = false;
+  // Every LDS read of the loop body is unconditional (the last K-step of the work list reads a stale stage into F0 and takes one
+  // more barrier): a conditional ds_read makes the compiler's waitcnt pass fall back to lgkmcnt(0) at the join, which would
+  // expose the F0 read latency in front of every MFMA(F1) block.
+  for (int step = 0; step < total_steps; ++step) {
+    load_frags(F1, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(F0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = cur == NS - 1 ? 0 : cur + 1;
+    // stage s+1 must have landed; `ahead` counts the stages in flight including it (steady state: two)
+    wait_dma(ahead >= 2 && !drained);
+    drained = false;
+    --ahead;
+    load_frags(F0, nxt, 0);
+    const bool refill = more;
+    if (refill && issue_first) issue_step(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(F1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (refill) {
+      if (!issue_first) issue_step(cur);
+      more = advance_loader();
+      ++ahead;
+    }
+    prefetch_tap();
     if (--c_left == 0) {
       epilogue(cw);
       drained = true;
       cw += Gx;
-      if (cw >= w_end) done = true;
-      else {
+      if (cw < w_end) {
+        prefetch_bias(cw);
         c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
         zero_acc();
       }
     }
-    if (done) break;
-    wait_dma(issued && !drained);
-    cur = cur == NS - 1 ? 0 : cur + 1;
+    cur = nxt;
   }
 }
 
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
 hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = NS * (BM + BN) * 128 + 256;   // + per-tap table (<= 64 taps)
+  constexpr int lds = NS * (BM + BN) * 128 + 256;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets)
   static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -402,13 +502,16 @@ hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
 template <int WM, int WN, int TM, int TN, int NS, bool FE>
 hipError_t run_big_fe(const ConvGemmParams& p, hipStream_t stream) {
   const bool fast = (p.cin & 63) == 0 && p.shift == 0 && p.ntaps <= 32;
-  if (!FE) return run_big_fe2<WM, WN, TM, TN, NS, FE, 2>(p, stream);
   return fast ? run_big_fe2<WM, WN, TM, TN, NS, FE, 1>(p, stream) : run_big_fe2<WM, WN, TM, TN, NS, FE, 0>(p, stream);
 }
 template <int WM, int WN, int TM, int TN, int NS>
 hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
+  // Two instantiations per tile.  The batched epilogue (FE: prefetched bias, all residual loads issued together, 16-byte stores)
+  // saves ~15 us per work item over the generic one, but its instantiation runs the K loop ~0.18 us per K-step slower on
+  // L2-resident operands (register allocation; same loop source, same instruction mix).  Break-even ~80-100 K-steps per item,
+  // measured on the same device with tools/ab_ops.sh: FE always -> 1162 ms of conv per bench step, FE <= 100 steps -> 1146 ms.
   const int steps_per_item = (p.K / 64 + p.ksplit - 1) / p.ksplit;
-  return steps_per_item <= 24 ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
+  return steps_per_item <= 100 ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
 }
 
 }  // namespace
