@@ -115,6 +115,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   // the epilogue moves 16 bytes per lane (4 lanes = 64 contiguous bytes per pixel) instead of 8.  An odd last tile keeps the plain
   // layout; GEGLU has its own (hidden | gate) pairing.  The permutation costs nothing: it only changes which weight row a DMA
   // lane fetches.
+  const bool pointwise = fast && p.ntaps == 1 && p.stride == 1 && p.H == p.Ho && p.W == p.Wo && taps[0] == ((32 << 6) | 32);
   const bool pair_cols = !(p.flags & CF_GEGLU);
   constexpr int TNP = TN & ~1;
   auto chan_of_row = [&](int R) {
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
       const int m = m0 + r0 + RPT * i;
       unsigned tm = 0;
       int pb = 0, y0 = -1000000, x0 = 0;
-      if (m < p.M) {
+      if (pointwise) {
+        // 1x1 / linear layers (the shallow-K items, where per-item setup is exposed): output row == input row, one tap, no padding
+        if (m < p.M) { pb = m * p.x_ld * 2 + j * 16; tm = 1u; }
+      } else if (m < p.M) {
         const int b = m / HoWo;
         const int rem = m - b * HoWo;
         const int oy = rem / p.Wo;
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
       wrow[i] = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)((half ? jh : j) * 8)) * 2u : OOB;   // bytes
     }
     if (fast) {
-      l_chunk = l_kt / p.ntaps;
-      l_tap = l_kt - l_chunk * p.ntaps;
+      l_chunk = pointwise ? l_kt : l_kt / p.ntaps;
+      l_tap = pointwise ? 0 : l_kt - l_chunk * p.ntaps;
     }
   };
   // byte offset of the loader's tap, read one K-step before issue_step consumes it (unconditional: see the note on the peeled step)
