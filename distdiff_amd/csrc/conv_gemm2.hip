@@ -270,15 +270,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   };
   const float* bias = p.bias;
   if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
-  // bias of the item's columns, fetched when the item STARTS (right after the previous item's stores, where the pipeline waits with
-  // vmcnt(0) anyway) so that the epilogue begins without a dependent global load
-  float4 bv[TN];
-  auto prefetch_bias = [&](int w) {
-    const int n0 = ((w / p.ksplit) % ntn) * BN;
-    const bool ok = (p.flags & CF_BIAS) && p.ksplit == 1 && pair_cols && (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.N & 7);
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) bv[jn] = ok ? *(const float4*)(bias + n0 + wn * (TN * 16) + col_of(jn)) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
   auto epilogue = [&](int w) {
     const int kz = w % p.ksplit, tile = w / p.ksplit;
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -310,8 +301,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
     const bool tile_full = (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.y_ld & 7) && !(p.N & 7);
     const int fl = p.flags;
     if (tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
-      // bias was prefetched into bv[] when the item started (prefetch_bias); 16-byte loads / stores per tile pair
+      // 16-byte loads / stores per tile pair; bias and every residual row are requested before the first use.  (Keeping the
+      // bias in registers from the start of the item was measured slower: 20 VGPRs live across the K loop, tools/ab_ops.sh.)
       const int wb = n0 + wn * (TN * 16);
+      float4 bv[TN];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bv[jn] = (fl & CF_BIAS) ? *(const float4*)(bias + wb + col_of(jn)) : make_float4(0.f, 0.f, 0.f, 0.f);
       const int cp = wb + fq * 8, co = wb + (TN - 1) * 16 + fq * 4;       // pair t: cp + 32 t ; odd last tile: co
       uint4 rvp[TM][TN / 2];
       uint2 rvo[TM];
@@ -435,7 +430,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   int c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
   int total_steps = 0;                                // K-steps of this workgroup's whole work list
   for (int w = w_first; w < w_end; w += Gx) total_steps += min(ksteps, (w % p.ksplit) * per + per) - (w % p.ksplit) * per;
-  prefetch_bias(w_first);
   setup_loader(lw);
   prefetch_tap();
   issue_step(0);
@@ -481,7 +475,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
       drained = true;
       cw += Gx;
       if (cw < w_end) {
-        prefetch_bias(cw);
         c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
         zero_acc();
       }
@@ -510,7 +503,7 @@ hipError_t run_big_fe(const ConvGemmParams& p, hipStream_t stream) {
 }
 template <int WM, int WN, int TM, int TN, int NS>
 hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
-  // Two instantiations per tile.  The batched epilogue (FE: prefetched bias, all residual loads issued together, 16-byte stores)
+  // Two instantiations per tile.  The batched epilogue (FE: bias and all residual loads issued together, 16-byte stores)
   // saves ~15 us per work item over the generic one, but its instantiation runs the K loop ~0.18 us per K-step slower on
   // L2-resident operands (register allocation; same loop source, same instruction mix).  Break-even ~80-100 K-steps per item,
   // measured on the same device with tools/ab_ops.sh: FE always -> 1162 ms of conv per bench step, FE <= 100 steps -> 1146 ms.
