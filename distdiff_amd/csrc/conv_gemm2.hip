@@ -508,7 +508,8 @@ hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
   // L2-resident operands (register allocation; same loop source, same instruction mix).  Break-even ~80-100 K-steps per item,
   // measured on the same device with tools/ab_ops.sh: FE always -> 1162 ms of conv per bench step, FE <= 100 steps -> 1146 ms.
   const int steps_per_item = (p.K / 64 + p.ksplit - 1) / p.ksplit;
-  return steps_per_item <= 100 ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
+  // split-K items only store fp32 partials (same code in both instantiations): take the faster loop
+  return (steps_per_item <= 100 && p.ksplit == 1) ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
 }
 
 }  // namespace
