@@ -428,8 +428,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   };
   int cw = w_first;                                   // compute iterator
   int c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
-  int total_steps = 0;                                // K-steps of this workgroup's whole work list
-  for (int w = w_first; w < w_end; w += Gx) total_steps += min(ksteps, (w % p.ksplit) * per + per) - (w % p.ksplit) * per;
   setup_loader(lw);
   prefetch_tap();
   issue_step(0);
@@ -446,40 +444,40 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   int cur = 0;
   bool drained = false;
   // Every LDS read of the loop body is unconditional (the last K-step of the work list reads a stale stage into F0 and takes one
-  // more barrier): a conditional ds_read makes the compiler's waitcnt pass fall back to lgkmcnt(0) at the join, which would
+  // more barrier; `ahead` may go negative there, which only selects the vmcnt(0) form of the wait): a conditional ds_read makes the compiler's waitcnt pass fall back to lgkmcnt(0) at the join, which would
   // expose the F0 read latency in front of every MFMA(F1) block.
-  for (int step = 0; step < total_steps; ++step) {
-    load_frags(F1, cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(F0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int nxt = cur == NS - 1 ? 0 : cur + 1;
-    // stage s+1 must have landed; `ahead` counts the stages in flight including it (steady state: two)
-    wait_dma(ahead >= 2 && !drained);
-    drained = false;
-    --ahead;
-    load_frags(F0, nxt, 0);
-    const bool refill = more;
-    if (refill && issue_first) issue_step(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(F1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (refill) {
-      if (!issue_first) issue_step(cur);
-      more = advance_loader();
-      ++ahead;
-    }
-    prefetch_tap();
-    if (--c_left == 0) {
-      epilogue(cw);
-      drained = true;
-      cw += Gx;
-      if (cw < w_end) {
-        c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
-        zero_acc();
+  while (true) {
+    // K loop of one work item (the loader is up to three K-steps ahead, possibly already in the next item)
+    for (int left = c_left; left > 0; --left) {
+      load_frags(F1, cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(F0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int nxt = cur == NS - 1 ? 0 : cur + 1;
+      // stage s+1 must have landed; `ahead` counts the stages in flight including it (steady state: two)
+      wait_dma(ahead >= 2 && !drained);
+      drained = false;
+      --ahead;
+      load_frags(F0, nxt, 0);
+      const bool refill = more;
+      if (refill && issue_first) issue_step(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(F1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (refill) {
+        if (!issue_first) issue_step(cur);
+        more = advance_loader();
+        ++ahead;
       }
+      prefetch_tap();
+      cur = nxt;
     }
-    cur = nxt;
+    epilogue(cw);
+    drained = true;
+    cw += Gx;
+    if (cw >= w_end) break;
+    c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
+    zero_acc();
   }
 }
 
@@ -508,8 +506,11 @@ hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
   // L2-resident operands (register allocation; same loop source, same instruction mix).  Break-even ~80-100 K-steps per item,
   // measured on the same device with tools/ab_ops.sh: FE always -> 1162 ms of conv per bench step, FE <= 100 steps -> 1146 ms.
   const int steps_per_item = (p.K / 64 + p.ksplit - 1) / p.ksplit;
+#ifndef DD_FE_LIMIT
+#define DD_FE_LIMIT 100
+#endif
   // split-K items only store fp32 partials (same code in both instantiations): take the faster loop
-  return (steps_per_item <= 100 && p.ksplit == 1) ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
+  return (steps_per_item <= DD_FE_LIMIT && p.ksplit == 1) ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
 }
 
 }  // namespace
