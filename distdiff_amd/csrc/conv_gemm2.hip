@@ -115,7 +115,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   // the epilogue moves 16 bytes per lane (4 lanes = 64 contiguous bytes per pixel) instead of 8.  An odd last tile keeps the plain
   // layout; GEGLU has its own (hidden | gate) pairing.  The permutation costs nothing: it only changes which weight row a DMA
   // lane fetches.
-  const bool pointwise = fast && p.ntaps == 1 && p.stride == 1 && p.H == p.Ho && p.W == p.Wo && taps[0] == ((32 << 6) | 32);
+  // (read through readfirstlane: a value loaded from LDS is "divergent" to the compiler, and a divergent `pointwise` would push the
+  //  tap / chunk counters into VGPRs and turn every buffer_load's scalar offset into a waterfall loop)
+  const bool pointwise = fast && p.ntaps == 1 && p.stride == 1 && p.H == p.Ho && p.W == p.Wo &&
+                         __builtin_amdgcn_readfirstlane(taps[0]) == ((32 << 6) | 32);
   const bool pair_cols = !(p.flags & CF_GEGLU);
   constexpr int TNP = TN & ~1;
   auto chan_of_row = [&](int R) {
@@ -167,8 +170,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
       wrow[i] = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)((half ? jh : j) * 8)) * 2u : OOB;   // bytes
     }
     if (fast) {
-      l_chunk = pointwise ? l_kt : l_kt / p.ntaps;
-      l_tap = pointwise ? 0 : l_kt - l_chunk * p.ntaps;
+      // (explicitly scalar: the division runs on the VALU, and a VGPR-resident counter turns every buffer_load's scalar offset
+      //  into a readfirstlane waterfall loop)
+      l_chunk = __builtin_amdgcn_readfirstlane(pointwise ? l_kt : l_kt / p.ntaps);
+      l_tap = l_kt - l_chunk * p.ntaps;
     }
   };
   // byte offset of the loader's tap, read one K-step before issue_step consumes it (unconditional: see the note on the peeled step)
