@@ -148,7 +148,9 @@ def main():
     if distributed:
         weights = broadcast_weights(weights, cfg, src=0, device=dev)   # RCCL broadcast over xGMI
     guided = a.guidance != "none"
-    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=max(1, a.guidance_period), device=str(dev))
+    # transform guidance chains P guided steps (P activation stashes); a direct-guidance step is differentiated on its own (one)
+    stash = max(1, a.guidance_period) if a.guidance == "transform_guidance" else 1
+    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=str(dev))
     sched = DDIMSchedule(cfg.scheduler)
     ts = sched.set_timesteps(a.schedule_steps)
     eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=7.5, gs=1.0, ls=1.0, rho=10.0,

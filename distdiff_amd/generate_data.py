@@ -302,7 +302,9 @@ def build_engine(args):
                    "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder", ("model.safetensors",)).items()
                             if "position_ids" not in k}}
     guided = bool(args.guidance_type)
-    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=max(1, args.guidance_period), device=args.device or "cuda:0")
+    # transform_guidance differentiates through P chained steps (P activation stashes); direct_guidance one step at a time
+    stash = max(1, args.guidance_period) if args.guidance_type == "transform_guidance" else 1
+    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=args.device or "cuda:0")
     sched = DDIMSchedule(cfg.scheduler)
     ts = sched.set_timesteps(args.steps)
     targets = (args.optimize_targets or "").split("-")
