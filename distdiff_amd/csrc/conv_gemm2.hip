@@ -9,6 +9,7 @@
 //     double-buffered pipeline running ACROSS items, so the first global-load latency and the epilogue of an item
 //     overlap the next item's loads: this is what fixes the shallow-K layers (K = 320: 5 K-steps per tile).
 //   * work items are dealt to XCDs in contiguous chunks (blocks b, b+8, ... share an L2) with n-tiles fastest.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "conv_epilogue.h"
@@ -30,7 +31,7 @@ __device__ __forceinline__ void dma16(const void* base, void* lds, unsigned voff
 // FM: 1 = scalar-tap fast path compiled in, 0 = general path only, 2 = chosen at run time. The compile-time forms help the
 // shallow-K (FE) instantiation by 5-6 %, the run-time form is 1-6 % faster on deep-K shapes (same-device A/B): compiler scheduling.
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
-__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm_big_kernel(ConvGemmParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int NW = WM * WN;   // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512-register budget, 128x128+ per wave)
   constexpr int NT = NW * 64;
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   // so no LDS latency is exposed to the MFMA stream, the stage of step s is re-filled as soon as its reads are issued (the loader
   // runs three K-steps ahead, across work items) and there is one barrier per K-step.  vmcnt counts every VMEM op of the wave in
   // issue order, so after an epilogue (whose loads/stores interleave with the DMAs) the next wait drains with vmcnt(0).
-  static_assert(NS == 3, "three stages");
+  // NS = 2 (the 4-wave form, two workgroups per CU): the stage of step s is re-filled with step s+2 and every wait is vmcnt(0);
+  // the second workgroup of the CU covers the shorter prefetch distance and, above all, the other one's epilogue.
   auto wait_dma = [&](bool keep_one_stage) {
     if (keep_one_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,13 +441,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_big_kernel(ConvGemmPara
   bool more = advance_loader();
   prefetch_tap();
   int ahead = 0;                                      // DMA stages in flight (after the first wait: including the one needed next)
-  if (more) { issue_step(1); more = advance_loader(); prefetch_tap(); ahead = 1; }
+  if (NS == 3 && more) { issue_step(1); more = advance_loader(); prefetch_tap(); ahead = 1; }
   wait_dma(ahead == 1);
-  if (more) { issue_step(2); more = advance_loader(); prefetch_tap(); ahead = 2; }
+  if (more) { issue_step(NS - 1); more = advance_loader(); prefetch_tap(); ahead = NS - 1; }
   zero_acc();
   Frags F0, F1;
   load_frags(F0, 0, 0);
-  const bool issue_first = wave < 4;                  // SIMD partners run DMA issue and MFMAs in opposite order
+  const bool issue_first = NW == 4 || wave < 4;       // 8 waves: SIMD partners run DMA issue and MFMAs in opposite order
   int cur = 0;
   bool drained = false;
   // Every LDS read of the loop body is unconditional (the last K-step of the work list reads a stale stage into F0 and takes one
@@ -494,7 +496,8 @@ hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int W = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit;
-  int G = W < 256 ? (W + 7) / 8 * 8 : 256;
+  constexpr int WGS = 256 * ((WM * WN == 4) ? 2 : 1);   // persistent: one 8-wave or two 4-wave workgroups per CU
+  int G = W < WGS ? (W + 7) / 8 * 8 : WGS;
   hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM>), dim3(G), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
@@ -524,6 +527,14 @@ hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
 int conv_gemm_big_config(int M, int N, int K, int flags) {
   if (M < 1024 || N < 64 || K < 128) return 0;
   const bool geglu = (flags & CF_GEGLU) != 0;
+  // Items of up to ~100 K-steps run as two independent 4-wave workgroups per CU (NS = 2, half the tile): one workgroup's epilogue
+  // and pipeline refill overlap the other's MFMAs, which a single 8-wave workgroup in lock step cannot do.  Same-device A/B on
+  // the bench workload (tools/ab_ops.sh): conv 1078 -> 1029 ms per step; deeper items and the big VAE shapes prefer the larger
+  // tile (arithmetic intensity).  DD_CONV_2WG / DD_CONV_2WG128 override the K-step limits (0 disables) for A/B runs.
+  static const int two_wg = getenv("DD_CONV_2WG") ? atoi(getenv("DD_CONV_2WG")) : 100;
+  if (two_wg > 0 && K / 64 <= two_wg && !geglu && N % 160 == 0) return 4;              // 128 x 160, 4 waves, 2 per CU
+  static const int two_wg128 = getenv("DD_CONV_2WG128") ? atoi(getenv("DD_CONV_2WG128")) : 24;
+  if (two_wg128 > 0 && K / 64 <= two_wg128 && N % 128 == 0 && (geglu || N % 160 != 0)) return 5;   // 128 x 128, 4 waves, 2 per CU
   if (N <= 128) return 3;                          // 256 x 128
   if (!geglu && N % 160 == 0 && (N % 256 != 0 || N == 1280)) return 2;   // 256 x 160
   if (N % 256 == 0 || N >= 1024) return 1;         // 128 x 256
@@ -532,8 +543,8 @@ int conv_gemm_big_config(int M, int N, int K, int flags) {
 }
 
 void conv_gemm_big_tile(int cfg, int* bm, int* bn) {
-  *bm = cfg == 1 ? 128 : 256;
-  *bn = cfg == 1 ? 256 : cfg == 2 ? 160 : 128;
+  *bm = (cfg == 1 || cfg == 4 || cfg == 5) ? 128 : 256;
+  *bn = cfg == 1 ? 256 : (cfg == 2 || cfg == 4) ? 160 : 128;
 }
 
 hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream) {
@@ -542,6 +553,8 @@ hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t st
     case 1: return run_big<2, 4, 4, 4, 3>(p, stream);    // 128 x 256, 8 waves
     case 2: return run_big<4, 2, 4, 5, 3>(p, stream);    // 256 x 160, 8 waves
     case 3: return run_big<4, 2, 4, 4, 3>(p, stream);    // 256 x 128, 8 waves
+    case 4: return run_big<2, 2, 4, 5, 2>(p, stream);    // 128 x 160, 4 waves, two workgroups per CU (shallow K)
+    case 5: return run_big<2, 2, 4, 4, 2>(p, stream);    // 128 x 128, 4 waves, two workgroups per CU (GEGLU / N % 128 == 0)
     default: return hipErrorInvalidValue;
   }
 }

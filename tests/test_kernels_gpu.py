@@ -57,6 +57,13 @@ CONV_CASES = [
     ("big_stride2", 2, 64, 256, 64, 64, 3, 2, 1, 0),
     ("big_1x1_shallowK", 2, 320, 640, 32, 32, 1, 1, 0, 0),
     ("big_deepK_splitk", 2, 1280, 320, 24, 24, 3, 1, 1, 0),
+    # <= 100 (N % 160 == 0) / <= 24 (N % 128 == 0) K-steps run as two 4-wave workgroups per CU (128x160 / 128x128, 2 LDS stages);
+    # deeper items keep the 8-wave 128x256 / 256x160 / 256x128 forms: one case per form and per epilogue variant
+    ("big8_128x256_deepK", 2, 512, 256, 24, 24, 3, 1, 1, 0),
+    ("big8_256x128_deepK", 2, 512, 128, 32, 32, 3, 1, 1, 0),
+    ("big8_256x160_100steps", 4, 768, 160, 32, 32, 3, 1, 1, 0),
+    ("big4_128x160_pointwise", 4, 1280, 320, 32, 32, 1, 1, 0, 0),
+    ("big4_128x128_ragged", 3, 128, 384, 20, 21, 3, 1, 1, 0),
 ]
 
 
