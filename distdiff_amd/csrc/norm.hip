@@ -183,58 +183,68 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p,
     }
   }
   __syncthreads();
-  const int total = p.HW * VC;
-  const int stride = gridDim.x * GN_THREADS;
-  for (int idx0 = blockIdx.x * GN_THREADS + threadIdx.x; idx0 < total; idx0 += 4 * stride) {
-    uint4 xr[4], dr[4], orr[4];
+  // a thread owns one 8-channel vector column and walks rows: its 8 (or 48) coefficients live in registers for the whole sweep, no
+  // per-vector index division, no LDS traffic in the streaming loop (the kernel was VALU/LDS-bound at ~2.8 TB/s before)
+  const int VCt = min(VC, GN_THREADS);
+  const int R = GN_THREADS / VCt;
+  const int my_r = threadIdx.x / VCt, my_vc0 = threadIdx.x % VCt;
+  if (my_r >= R) return;
+  const int rstep = gridDim.x * R;
+  for (int vc = my_vc0; vc < VC; vc += VCt) {
+    float ca[8], cb[8], cc[8], cd[8], ce[8], cf[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = idx0 + u * stride;
-      if (idx < total) {
-        const int row = idx / VC, vc = idx - row * VC;
-        const size_t pix = (size_t)b * p.HW + row;
-        xr[u] = *(const uint4*)(p.x + pix * p.x_ld + vc * 8);
-        if (BWD) {
-          dr[u] = *(const uint4*)(p.dy + pix * p.dy_ld + vc * 8);
-          if (p.accumulate) orr[u] = *(const uint4*)(p.dx + pix * p.dx_ld + vc * 8);
+    for (int e = 0; e < 8; ++e) {
+      const int c = vc * 8 + e;
+      ca[e] = A[c]; cb[e] = Bv[c];
+      if (BWD) { cc[e] = Cv[c]; cd[e] = Dv[c]; ce[e] = Ev[c]; cf[e] = Fv[c]; }
+    }
+    for (int row0 = blockIdx.x * R + my_r; row0 < p.HW; row0 += 4 * rstep) {
+      uint4 xr[4], dr[4], orr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u * rstep;
+        if (row < p.HW) {
+          const size_t pix = (size_t)b * p.HW + row;
+          xr[u] = *(const uint4*)(p.x + pix * p.x_ld + vc * 8);
+          if (BWD) {
+            dr[u] = *(const uint4*)(p.dy + pix * p.dy_ld + vc * 8);
+            if (p.accumulate) orr[u] = *(const uint4*)(p.dx + pix * p.dx_ld + vc * 8);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = idx0 + u * stride;
-      if (idx >= total) continue;
-      const int row = idx / VC, vc = idx - row * VC;
-      const size_t pix = (size_t)b * p.HW + row;
-      float xv[8], ov[8];
-      unpack8(xr[u], xv);
-      if (!BWD) {
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u * rstep;
+        if (row >= p.HW) continue;
+        const size_t pix = (size_t)b * p.HW + row;
+        float xv[8], ov[8];
+        unpack8(xr[u], xv);
+        if (!BWD) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = vc * 8 + e;
-          const float y = xv[e] * A[c] + Bv[c];
-          ov[e] = p.silu ? silu_f(y) : y;
+          for (int e = 0; e < 8; ++e) {
+            const float y = xv[e] * ca[e] + cb[e];
+            ov[e] = p.silu ? silu_f(y) : y;
+          }
+          *(uint4*)(p.y + pix * p.y_ld + vc * 8) = pack8(ov);
+        } else {
+          float dv[8];
+          unpack8(dr[u], dv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - cb[e]) * cc[e];
+            float d = dv[e];
+            if (p.silu) d *= dsilu_f(xh * ca[e] + cf[e]);
+            d *= ca[e];
+            ov[e] = cc[e] * (d - cd[e] - xh * ce[e]);
+          }
+          if (p.accumulate) {
+            float old[8];
+            unpack8(orr[u], old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] += old[e];
+          }
+          *(uint4*)(p.dx + pix * p.dx_ld + vc * 8) = pack8(ov);
         }
-        *(uint4*)(p.y + pix * p.y_ld + vc * 8) = pack8(ov);
-      } else {
-        float dv[8];
-        unpack8(dr[u], dv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = vc * 8 + e;
-          const float xh = (xv[e] - Bv[c]) * Cv[c];
-          float d = dv[e];
-          if (p.silu) d *= dsilu_f(xh * A[c] + Fv[c]);
-          d *= A[c];
-          ov[e] = Cv[c] * (d - Dv[c] - xh * Ev[c]);
-        }
-        if (p.accumulate) {
-          float old[8];
-          unpack8(orr[u], old);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] += old[e];
-        }
-        *(uint4*)(p.dx + pix * p.dx_ld + vc * 8) = pack8(ov);
       }
     }
   }
