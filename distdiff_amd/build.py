@@ -15,7 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libdistdiff_hip.so")
 SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "norm.hip", "attention.hip", "elementwise.hip", "weights.cpp", "ops_abi.cpp", "engine.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3"] + os.environ.get("DD_EXTRA_CFLAGS", "").split() + ["-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs. With the default heuristic the attention kernels put them in AccVGPRs
+# and paid 144 v_accvgpr_read/write per KV tile to run the softmax on them (found in the ISA; attention family 475 -> see DESIGN.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("DD_EXTRA_CFLAGS", "").split() + ["-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
          "-I", os.path.join(HERE, "..", "include")]
 
 
