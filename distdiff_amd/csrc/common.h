@@ -14,8 +14,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN preserved
   return __builtin_bit_cast(unsigned short, h);
 }
+// two floats -> one dword of two bf16 (lo in bits 0-15): a single v_cvt_pk_bf16_f32 (RNE), not two conversions + shift + or
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
