@@ -39,20 +39,22 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, u);
 }
 // stage ROWS x DPK bf16 (zero padded beyond D columns / nvalid rows) into LDS with row stride S bytes
-template <int ROWS, int DPK>
+// ONES: column D of the tile (a padding column) is set to 1.0, so that P.V also accumulates the softmax row sums (forward V tile)
+template <int ROWS, int DPK, bool ONES = false>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, int S, const bf16_t* g, int ld, int nvalid, int D, int tid) {
   constexpr int VPR = DPK / 8;
   for (int idx = tid; idx < ROWS * VPR; idx += 256) {
     const int r = idx / VPR, v = idx % VPR;
     uint4 val = make_uint4(0, 0, 0, 0);
     if (r < nvalid && v * 8 < D) val = *(const uint4*)(g + (size_t)r * ld + v * 8);
+    if (ONES && v * 8 == D) val.x = 0x3f80u;
     *(uint4*)(lds + r * S + v * 16) = val;
   }
 }
 // register-staged variant: issue the global loads of a tile early, write them to LDS after the compute of the previous tile
 template <int ROWS, int DPK>
 struct TileRegs { uint4 v[(ROWS * (DPK / 8) + 255) / 256]; };
-template <int ROWS, int DPK>
+template <int ROWS, int DPK, bool ONES = false>
 __device__ __forceinline__ void tile_load(TileRegs<ROWS, DPK>& t, const bf16_t* g, int ld, int nvalid, int D, int tid) {
   constexpr int VPR = DPK / 8, N = (ROWS * VPR + 255) / 256;
 #pragma unroll
@@ -61,6 +63,7 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS, DPK>& t, const bf16_t* 
     const int r = idx / VPR, v = idx % VPR;
     uint4 val = make_uint4(0, 0, 0, 0);
     if (idx < ROWS * VPR && r < nvalid && v * 8 < D) val = *(const uint4*)(g + (size_t)r * ld + v * 8);
+    if (ONES && v * 8 == D) val.x = 0x3f80u;
     t.v[i] = val;
   }
 }
@@ -136,10 +139,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // K/V tiles are register-staged one tile ahead (global latency hides under the MFMAs of the current tile) for the small
   // head dims; d = 512 keeps the direct staging (its tile would need 64 staging VGPRs)
   constexpr bool PREFETCH = (DPK <= 160);
+  // head dims with a padded column inside the last 16-wide output tile (d = 40): that column of V is set to 1.0, so the P.V MFMAs
+  // also deliver the softmax row sums (of exactly the bf16 P the outputs are built from) and the 16 VALU adds per query tile and
+  // KV tile disappear -- the forward is VALU-bound at d = 40
+  constexpr bool ONES = DSPLIT == 1 && (D % 16) != 0 && (D % 8) == 0;
   TileRegs<KT, PREFETCH ? DPK : 32> kreg, vreg;
   if (PREFETCH) {
     tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
-    tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg, p.ldv, p.Nk, D, tid);
+    tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg, p.ldv, p.Nk, D, tid);
   }
   for (int k0 = 0; k0 < p.Nk; k0 += KT) {
     __syncthreads();
@@ -148,12 +155,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       tile_store<KT, PREFETCH ? DPK : 32>(vreg, Vs, S, tid);
     } else {
       stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
-      stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+      stage_tile<KT, DPK, ONES>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
     }
     __syncthreads();
     if (PREFETCH && k0 + KT < p.Nk) {
       tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg + (size_t)(k0 + KT) * p.ldk, p.ldk, p.Nk - k0 - KT, D, tid);
-      tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg + (size_t)(k0 + KT) * p.ldv, p.ldv, p.Nk - k0 - KT, D, tid);
+      tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg + (size_t)(k0 + KT) * p.ldv, p.ldv, p.Nk - k0 - KT, D, tid);
     }
     f32x4 st[QT][NKT];
 #pragma unroll
@@ -180,11 +187,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           for (int r = 0; r < 4; ++r)
             if (k0 + kt * 16 + 4 * g + r >= klim[qt]) st[qt][kt][r] = -INFINITY;
       }
-      float mx = st[qt][0][0];
+      // three-input maxima (v_max3_f32): 4 values per key tile -> one max3 + one max, then a max3 tree over the tiles
+      float mt[NKT];
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt) mt[kt] = fmaxf(fmaxf(fmaxf(st[qt][kt][0], st[qt][kt][1]), st[qt][kt][2]), st[qt][kt][3]);
+      float mx = mt[0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+      for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, mt[kt]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
@@ -196,9 +205,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 4; ++r) {
           const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
           st[qt][kt][r] = e;
-          ps += e;
+          if (!ONES) ps += e;
         }
-      lsum[qt] = lsum[qt] * alpha + ps;
+      if (!ONES) lsum[qt] = lsum[qt] * alpha + ps;
       mrun[qt] = mnew;
       if (__any(alpha != 1.f)) {                              // wave-uniform: skip the O rescale when no row max moved
 #pragma unroll
@@ -218,9 +227,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = lsum[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (ONES) {
+      // row sums sit in the ones column: output row D % 16 of the last tile = lane group (D % 16) / 4, register (D % 16) % 4
+      l = __shfl(o[qt][DTW - 1][(D % 16) % 4], ((D % 16) / 4) * 16 + i16, 64);
+    } else {
+      l = lsum[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     if (qrow[qt] >= p.Nq) continue;
     const float inv = 1.f / l;
     bf16_t* op = p.o + ((size_t)b * p.Nq + qrow[qt]) * p.ldo + h * D;
