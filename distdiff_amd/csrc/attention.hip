@@ -187,13 +187,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           for (int r = 0; r < 4; ++r)
             if (k0 + kt * 16 + 4 * g + r >= klim[qt]) st[qt][kt][r] = -INFINITY;
       }
-      // three-input maxima (v_max3_f32): 4 values per key tile -> one max3 + one max, then a max3 tree over the tiles
-      float mt[NKT];
+      float mx = st[qt][0][0];
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) mt[kt] = fmaxf(fmaxf(fmaxf(st[qt][kt][0], st[qt][kt][1]), st[qt][kt][2]), st[qt][kt][3]);
-      float mx = mt[0];
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, mt[kt]);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
