@@ -1,14 +1,19 @@
-// K1/K2 (large shapes) — persistent big-tile implicit-GEMM convolution / linear on bf16 MFMA, gfx950.
+// K1/K2 (large shapes) — persistent implicit-GEMM convolution / linear on bf16 MFMA, gfx950.
 //
-// Same math, operand layout, LDS swizzle and epilogue as conv_gemm.hip, restructured for the shapes that
-// dominate the UNet / VAE time:
-//   * 8 waves (512 threads), tile BM x BN in {128x256, 256x160, 256x128}, 3 LDS stages (a 256x256 tile spills: 128 accumulator + ~140 staging/fragment VGPRs): 1.3-2x the arithmetic intensity of the
-//     128x128 tile, so the per-XCD L2 no longer bounds the MFMA rate (MI355X: ~56 B/clk/CU of L2 vs 4 kFLOP/clk/CU);
-//     BN = 160 removes the N-padding waste of the SD-1.x channel counts (320/640/960/1280/1920/...).
-//   * persistent: each workgroup walks a list of (tile, K-split) work items and keeps the LDS-DMA
-//     double-buffered pipeline running ACROSS items, so the first global-load latency and the epilogue of an item
-//     overlap the next item's loads: this is what fixes the shallow-K layers (K = 320: 5 K-steps per tile).
-//   * work items are dealt to XCDs in contiguous chunks (blocks b, b+8, ... share an L2) with n-tiles fastest.
+// Same math, operand layout, LDS swizzle and epilogue semantics as conv_gemm.hip, restructured for the shapes that dominate the
+// UNet / VAE time.  DESIGN.md section 3 describes the design and section 6 what was measured.
+//   * Two forms of one kernel template:
+//       8 waves, tiles 128x256 / 256x160 / 256x128, three LDS stages, one workgroup per CU  (items deeper than ~100 K-steps, big VAE shapes);
+//       4 waves, tiles 128x160 / 128x128, two LDS stages, TWO workgroups per CU            (shallow items: one group's epilogue and
+//       pipeline refill overlap the other's MFMAs).  BN = 160 removes the N-padding waste of the SD-1.x channel counts.
+//   * Staging is buffer_load_dwordx4 ... lds (LDS-DMA): per-lane byte offsets fixed per work item, the K-step moves through the scalar
+//     offset, out-of-range lanes are zero-filled by the hardware (padding taps, ragged rows).  The swizzle is applied on the source side.
+//   * The K loop is software-pipelined through registers (fragment sets F0/F1), one barrier per 64-wide K-step, every LDS read
+//     unconditional and every counter scalar (see the notes at the loop: both matter to what the compiler emits).
+//   * Persistent: each workgroup walks a list of (tile, K-split) work items with the loader running ahead into the next item; items are
+//     dealt to XCDs in contiguous chunks (blocks b, b+8, ... share an L2) with n-tiles fastest.
+//   * Epilogue: paired output columns -> 16-byte residual loads / stores; a batched form (FE) for short items, the generic
+//     Epi::apply form for deep / split-K items (its instantiation has the faster K loop).
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
@@ -28,12 +33,12 @@ __device__ __forceinline__ void dma16(const void* base, void* lds, unsigned voff
 #endif
 }
 
-// FM: 1 = scalar-tap fast path compiled in, 0 = general path only, 2 = chosen at run time. The compile-time forms help the
-// shallow-K (FE) instantiation by 5-6 %, the run-time form is 1-6 % faster on deep-K shapes (same-device A/B): compiler scheduling.
+// FM: 1 = fast staging path only (Cin % 64 == 0, no fused upsample / dilation, <= 32 taps: buffer loads with scalar tap offsets),
+//     0 = general path only (per-lane address arithmetic, global_load_lds).  FE: batched epilogue compiled in.
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm_big_kernel(ConvGemmParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int NW = WM * WN;   // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512-register budget, 128x128+ per wave)
+  constexpr int NW = WM * WN;   // 8 waves (one workgroup per CU) or 4 waves (two workgroups per CU, <= 256 VGPRs each)
   constexpr int NT = NW * 64;
   constexpr int RPT = NW * 8;   // tile rows per full staging pass: NT threads x 16 B = RPT rows of 128 B
   constexpr int AV = BM / RPT;  // A passes (all full)
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   const int r0 = tid >> 3;                    // tile row of staging pass 0
   const int rh = wave * 4 + (lane >> 3);      // row inside a half pass (lanes 0-31 only)
   const int jh = ps ^ (rh & 7);
-  const bool fast = FM == 2 ? (uniform_tap && shift == 0 && p.ntaps <= 32) : (FM == 1);   // host guarantees FM == 1 <=> that condition
+  constexpr bool fast = FM == 1;   // the host picks FM == 1 exactly when Cin % 64 == 0, shift == 0 and ntaps <= 32 (run_big_fe)
   // the per-tap offset table lives in LDS: a global load inside the pipeline would force s_waitcnt vmcnt(0)
   // (vmcnt retires in order) and drain the in-flight DMA stages
   int* taps = (int*)(smem + NS * BUF_BYTES);
