@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = k0 + kt * 16 + 4 * g + r;
-            const float pr = key < p.Nk ? exp2f(st[qt][kt][r] * sl2 - lse2[qt]) : 0.f;
+            const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[qt][kt][r] * sl2 - lse2[qt]) : 0.f;
             st[qt][kt][r] = pr * (dpt[qt][kt][r] - delta[qt]);
           }
 #pragma unroll
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = exp2f(s[kt][qt][r] * sl2 - l2[r]);
+            const float pr = __builtin_amdgcn_exp2f(s[kt][qt][r] * sl2 - l2[r]);
             s[kt][qt][r] = pr;
             dp[kt][qt][r] = pr * (dp[kt][qt][r] - de[r]);
           }
