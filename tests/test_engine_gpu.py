@@ -8,7 +8,9 @@ Tolerance statement (bf16 storage + bf16 MFMA inputs, fp32 accumulation, vs the 
       flip, torch's own bf16 autograd differs from fp32 by ~20 % on this network (tools/engine_check.py)
   (e, b) gradients of transform guidance (chained through the guide)   <= 40 % (same mask-flip noise)
   guidance scores                                                   <= 1 %
-  latents after guidance / after the whole loop                     <= 5 %, decoded image max abs error <= 0.15 (of [0,1])
+  latents after transform guidance                                  <= 8 % vs the reference (gradient-noise dominated: 3.8-5.8 % measured
+      across arithmetically equivalent builds), and == the update rule applied to the engine's own gradient to 2e-4
+  latents after direct guidance / after the whole loop              <= 5 %, decoded image max abs error <= 0.15 (of [0,1])
 """
 import os
 
@@ -111,8 +113,21 @@ def test_transform_guidance_vs_reference_fixture(setup, fx):
     first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
     z, score, gz0 = eng.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
     assert abs(score.item() - float(fx["ref_transform_score"])) < 0.01 * abs(float(fx["ref_transform_score"]))
-    assert rel(z, fx["ref_transform_z"]) < 0.05
     assert float((z.cpu() - fx["z"]).abs().max()) <= fx["args"]["constraint_value"] + 1e-5   # L-inf ball (generate_data.py:124-137)
+    # the update rule itself (:696, :721-728), exactly: e -= rho*ge, b -= rho*gb, re-affine, clamp (lower bound first) -- evaluated
+    # with the engine's own gradient, so this part is free of the gradient noise discussed below
+    a, z0, g0 = fx["args"], fx["z"], gz0.cpu()
+    e2 = fx["e"].reshape(-1, 4, 1, 1) - a["rho"] * (g0 * z0).sum((2, 3), keepdim=True)
+    b2 = fx["b"].reshape(-1, 4, 1, 1) - a["rho"] * g0.sum((2, 3), keepdim=True)
+    new = z0 * (1 + e2) + b2
+    lo, hi = z0 - a["constraint_value"], z0 + a["constraint_value"]
+    new = torch.where(new < lo, lo, new)
+    new = torch.where(new > hi, hi, new)
+    assert (z.cpu() - new).abs().max().item() < 2e-4
+    # against the reference's own output the latents inherit the noise of the chained VJP (ReLU masks of activations within bf16
+    # rounding of zero flip, module docstring): 0.038 - 0.058 was measured across arithmetically equivalent builds (a 1-ulp change
+    # anywhere re-draws the flips), so the bound carries that spread
+    assert rel(z, fx["ref_transform_z"]) < 0.08
     # gradient wrt (e, b) against the oracle's autograd
     args = O.SamplerArgs(**fx["args"])
     unet, vae, guide, sched = models
