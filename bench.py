@@ -125,6 +125,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries exactly ONE JSON line: everything else that libraries print there (RCCL writes its NCCL_DEBUG=VERSION banner to
+    # stdout when the first communicator is created) is sent to stderr by pointing fd 1 at fd 2 for the life of the process; the result
+    # line is written to a duplicate of the original stdout
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local)
@@ -246,7 +252,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, wcpu, n_exec, a.guidance_period, flops_per_image)
             except Exception as ex:  # the baseline is reported, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if distributed:
         import torch.distributed as dist
