@@ -76,6 +76,7 @@ CF_BIAS, CF_RES, CF_RELU, CF_GEGLU, CF_OUT_F32, CF_MASK, CF_RES_F32, CF_GEGLU_RA
 OPS_SYMBOLS = [
     "dd_op_conv_gemm", "dd_op_groupnorm_fwd", "dd_op_groupnorm_bwd", "dd_op_groupnorm_scratch_bytes",
     "dd_op_layernorm_fwd", "dd_op_layernorm_bwd", "dd_op_attention_fwd", "dd_op_attention_bwd",
+    "dd_op_attention_gemm_workspace", "dd_op_attention_gemm_fwd", "dd_op_attention_gemm_bwd",
     "dd_pack_conv_weight", "dd_op_nchw_f32_to_nhwc_bf16", "dd_op_nhwc_to_nchw_f32", "dd_op_cfg_ddim",
     "dd_op_cfg_ddim_bwd", "dd_op_sumpool2x2", "dd_op_geglu_bwd", "dd_op_maxpool3x3s2", "dd_op_maxpool3x3s2_bwd",
     "dd_op_bicubic", "dd_op_bicubic_bwd", "dd_op_gap", "dd_op_energy", "dd_op_transform_update", "dd_op_affine",

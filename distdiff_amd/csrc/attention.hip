@@ -564,6 +564,15 @@ hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
   }
 }
 
+hipError_t launch_attention_delta(const AttnParams& p, hipStream_t s) {
+  if (!p.delta || !p.d_o || !p.o) return hipErrorInvalidValue;
+  const size_t total = (size_t)p.B * p.H * p.Nq;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t s) {
   if (!attn_check(p) || (p.lddo & 7) || (p.lddq & 3) || !p.delta || !p.lse) return hipErrorInvalidValue;
   {

@@ -151,6 +151,8 @@ struct Ctx {  // per-call execution context
   char* scratch_partial = nullptr; size_t partial_cap = 0;
   char* scratch_tmp = nullptr;
   float* gn_scratch = nullptr;
+  const int* tap1x1 = nullptr;   // device int: the 1x1 tap, for GEMMs issued outside a ConvW (wide-head attention)
+  size_t tmp_cap = 0;
   int step_index = 0;
   int B = 0;             // live batch of this call (<= built batch)
   hipStream_t s = nullptr;
@@ -208,6 +210,7 @@ struct dd_engine {
   char* scratch_partial = nullptr; size_t partial_cap = 0;
   char* scratch_tmp = nullptr; size_t tmp_cap = 0;
   float* gn_scratch = nullptr;
+  int* tap1x1 = nullptr;
   float* f32_tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B,4,L,L] fp32 temporaries
   float* img_tmp = nullptr;    // [B,3,8L,8L] fp32
   float* score_tmp = nullptr;
@@ -385,6 +388,9 @@ struct Builder {
     int y = P.tensor(tq.B, tq.H, tq.W, tq.C);
     Op op; op.kind = OP_ATTN; op.q = q; op.k = k; op.v = v; op.y = y; op.heads = heads; op.D = tq.C / heads; op.Nq = Nq; op.Nk = Nk;
     op.cross_slot = cross_slot; op.causal = causal;
+    // wide heads (AutoencoderKL mid block) run through GEMMs on a materialised score matrix: per-image scratch (attention_gemm.hip)
+    if (op.D >= 256 && cross_slot < 0 && !causal)
+      P.scratch_tmp = std::max(P.scratch_tmp, attention_gemm_workspace(Nq, Nk, op.D, P.want_grad ? 1 : 0));
     op.stats_off = P.fp32_block((size_t)tq.B * heads * Nq * 2);  // lse + delta
     op.flops = 4.0 * tq.B * heads * (double)Nq * Nk * op.D;
     P.ops.push_back(op);
@@ -526,7 +532,10 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
         p.causal = op.causal;
-        HIPCHK(launch_attention_fwd(p, c.s));
+        if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 0) <= c.tmp_cap)
+          HIPCHK(launch_attention_gemm_fwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
+        else
+          HIPCHK(launch_attention_fwd(p, c.s));
         if (c.flops) *c.flops += op.flops;
       } break;
       case OP_CONCAT: {
@@ -636,7 +645,10 @@ void run_bwd(const Program& P, const Ctx& c) {
         p.delta = p.lse + (size_t)q.B * op.heads * op.Nq;
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
         p.d_o = grad_ptr(c, y); p.lddo = y.ld; p.dq = grad_ptr(c, q); p.lddq = q.ld;
-        HIPCHK(launch_attention_bwd(p, c.s));
+        if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 1) <= c.tmp_cap)
+          HIPCHK(launch_attention_gemm_bwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
+        else
+          HIPCHK(launch_attention_bwd(p, c.s));
         if (c.flops) *c.flops += op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5);
       } break;
       case OP_CONCAT: {
@@ -923,7 +935,7 @@ struct Run {
   dd_engine* E; hipStream_t s; int B;
   Ctx ctx(const Program&, char* act) {
     Ctx c; c.act = act; c.grad = E->grad_slab; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
-    c.scratch_tmp = E->scratch_tmp; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
+    c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
     return c;
   }
 };
@@ -1117,7 +1129,12 @@ int dd_finalize_weights(dd_engine* E) {
     E->partial_cap = std::max({E->unet.scratch_partial, E->vae.scratch_partial, E->guide.scratch_partial, E->venc.scratch_partial,
                                E->text.scratch_partial, (size_t)1 << 20});
     E->scratch_partial = (char*)E->dmalloc(E->partial_cap, false);
-    E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, (size_t)256});
+    E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, E->venc.scratch_tmp, E->text.scratch_tmp, (size_t)256});
+    if (!getenv("DD_ATTN_FLASH_ONLY")) {   // A/B switch: keep the flash kernels for wide heads too
+      const int tap = (32 << 6) | 32;
+      E->tap1x1 = (int*)E->dmalloc(sizeof(int), false);
+      HIPCHK(hipMemcpy(E->tap1x1, &tap, sizeof(int), hipMemcpyHostToDevice));
+    }
     E->scratch_tmp = (char*)E->dmalloc(E->tmp_cap);
     const int maxG = std::max(c.unet_groups, c.vae_groups);
     E->gn_scratch = (float*)E->dmalloc(groupnorm_scratch_bytes(2 * B, maxG), false);

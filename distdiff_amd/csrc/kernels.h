@@ -110,6 +110,14 @@ struct AttnParams {
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);
+hipError_t launch_attention_delta(const AttnParams& p, hipStream_t stream);   // delta[b,h,q] = sum_d dO*O (first stage of the backward)
+// Wide heads (d >= 256: the AutoencoderKL mid-block attention) through the GEMM kernel with a materialised N x N score matrix per image
+// (attention_gemm.hip).  workspace: attention_gemm_workspace() bytes; tap1x1: device int holding the 1x1 tap ((32 << 6) | 32);
+// partial: split-K scratch of launch_conv_gemm.  Same arguments / results as the flash launchers.
+bool attention_gemm_supported(const AttnParams& p);
+size_t attention_gemm_workspace(int Nq, int Nk, int D, int bwd);
+hipError_t launch_attention_gemm_fwd(const AttnParams& p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
+hipError_t launch_attention_gemm_bwd(const AttnParams& p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------
 // K6/K7/K9/K10/K12: small HBM-bound kernels.

@@ -38,6 +38,12 @@ int dd_op_layernorm_fwd(const struct LayerNormParams* p, void* stream);
 int dd_op_layernorm_bwd(const struct LayerNormParams* p, void* stream);
 int dd_op_attention_fwd(const struct AttnParams* p, void* stream);
 int dd_op_attention_bwd(const struct AttnParams* p, void* stream);
+/* wide heads (d >= 256, the AutoencoderKL mid-block attention): the same attention through GEMMs on a materialised N x N score
+ * matrix per image.  workspace: dd_op_attention_gemm_workspace() bytes of device scratch; tap1x1: device int = (32 << 6) | 32;
+ * partial / partial_cap: split-K scratch as for dd_op_conv_gemm. */
+size_t dd_op_attention_gemm_workspace(int Nq, int Nk, int D, int bwd);
+int dd_op_attention_gemm_fwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
+int dd_op_attention_gemm_bwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
 
 /* host-side weight packing: returns N, K, cin, ntaps through out[4]; wp may be NULL to query sizes */
 int dd_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu,

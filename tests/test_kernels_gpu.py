@@ -239,6 +239,30 @@ def test_attention(ops, case):
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
 
 
+@pytest.mark.parametrize("case", [("vae_mid_d512", 2, 1, 1024, 1024, 512), ("wide_2heads_d256", 1, 2, 512, 768, 256)], ids=lambda c: c[0])
+def test_attention_gemm_path(ops, case):
+    """wide heads through the GEMM kernel (attention_gemm.hip): same contract and tolerances as the flash kernels."""
+    name, B, H, Nq, Nk, D = case
+    g = torch.Generator().manual_seed(23)
+    q = bf(torch.randn(B, Nq, H, D, generator=g))
+    k = bf(torch.randn(B, Nk, H, D, generator=g))
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    scale = 1.0 / math.sqrt(D)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr)
+    d_o = bf(torch.randn(B, Nq, H, D, generator=g))
+    gq, gk, gv = torch.autograd.grad(ref, (qr, kr, vr), d_o)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    o, lse, dq, dk, dv = ops.attention_gemm(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale, d_o=dev(d_o, Nq))
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref.detach(), rtol=2e-2, atol=2e-3, what=name + " O")
+    assert_close(lse, torch.logsumexp(s.detach(), dim=-1), rtol=1e-3, atol=1e-3, what=name + " LSE")
+    assert_close(dq.reshape(B, Nq, H, D), gq, rtol=3e-2, atol=3e-3, what=name + " dQ")
+    assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what=name + " dK")
+    assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
+
+
 @pytest.mark.parametrize("case", [("clip_causal_77_d64", 3, 12, 77, 77, 64), ("causal_130_d64", 2, 2, 130, 130, 64)], ids=lambda c: c[0])
 def test_attention_causal(ops, case):
     """causal forward (CLIP text encoder: key j visible to query i iff j <= i)."""
