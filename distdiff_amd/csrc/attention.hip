@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
           }
         }
       }
+      const bool ragged = k0 + KT > p.Nk;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
@@ -350,7 +351,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = k0 + kt * 16 + 4 * g + r;
-            const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[qt][kt][r] * sl2 - lse2[qt]) : 0.f;
+            // keys beyond Nk only exist in the last tile of a ragged key count (wave-uniform test: no per-score select otherwise)
+            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -lse2[qt]));
+            if (ragged && key >= p.Nk) pr = 0.f;
             st[qt][kt][r] = pr * (dpt[qt][kt][r] - delta[qt]);
           }
 #pragma unroll
