@@ -309,6 +309,8 @@ int conv_gemm_pick_split(int M, int N, int K) {
 
 hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
   if (p.K & 63) return hipErrorInvalidValue;
+  // the kernels index the input with 32-bit element offsets (outputs and residuals use 64-bit offsets)
+  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0xFFFF0000ull) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   const int ksteps = p.K / 64;
   int cfg = ((p.force_small & 1) ? 0 : conv_gemm_big_config(p.M, p.N, p.K, p.flags));

@@ -509,7 +509,10 @@ hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
 
 template <int WM, int WN, int TM, int TN, int NS, bool FE>
 hipError_t run_big_fe(const ConvGemmParams& p, hipStream_t stream) {
-  const bool fast = (p.cin & 63) == 0 && p.shift == 0 && p.ntaps <= 32;
+  // the fast staging path addresses the input through 32-bit BYTE offsets of a buffer resource (plus the tap bias): inputs of
+  // 3.75 GB and more take the general path (32-bit ELEMENT offsets; launch_conv_gemm rejects inputs beyond those)
+  const size_t x_bytes = (size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2;
+  const bool fast = (p.cin & 63) == 0 && p.shift == 0 && p.ntaps <= 32 && x_bytes < 0xF0000000ull;
   return fast ? run_big_fe2<WM, WN, TM, TN, NS, FE, 1>(p, stream) : run_big_fe2<WM, WN, TM, TN, NS, FE, 0>(p, stream);
 }
 template <int WM, int WN, int TM, int TN, int NS>
