@@ -79,3 +79,52 @@ def test_latent_cache_format_and_reuse(hip_lib, tmp_path):
         assert ((got - ref).norm() / ref.norm()).item() < 0.03
     finally:
         eng.close()
+
+
+def test_prototype_extraction_from_image_files(hip_lib, tmp_path):
+    """8f-1 end to end (dataloader.py:664-747): image files -> HIP guide features -> class / group prototypes, against the oracle's
+    guide on the same preprocessed pixels and the same sklearn clustering."""
+    import types
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.prototypes import _load_image, extract_prototypes_with_encoder, prototypes_from_features
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    cfg = tiny_config(max_batch=4)
+    w = synthetic_weights(cfg, seed=0, num_classes=2)
+    rng = np.random.RandomState(4)
+    paths, targets = [], []
+    for i in range(10):                                    # 2 classes x 5 images of different sizes
+        p = str(tmp_path / ("c%d_%d.png" % (i % 2, i)))
+        Image.fromarray(rng.randint(0, 255, (40 + 7 * i, 64 + 3 * i, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+        targets.append(i % 2)
+    class _DS:
+        image_paths, class_names = paths, ["a", "b"]
+
+        def __len__(self):
+            return len(self.image_paths)
+
+    ds = _DS()
+    ds.targets = torch.tensor(targets)
+    eng = Engine(cfg, w, enable_grad=False, max_guidance_period=1)
+    try:
+        Pc, Pg = extract_prototypes_with_encoder(types.SimpleNamespace(K=2), eng, ds)
+    finally:
+        eng.close()
+    assert tuple(Pc.shape) == (2, cfg.guide.feature_dim) and tuple(Pg.shape) == (2, 2, cfg.guide.feature_dim)
+    guide = O.GuideOracle(cfg, w["guide"])
+    x = torch.stack([_load_image(p, cfg.guide.input_size) for p in paths])
+    with torch.no_grad():
+        f = guide.encode_image(x.to(torch.bfloat16).float())
+    f = f / f.norm(dim=-1, keepdim=True)
+    g_ref, l_ref = prototypes_from_features(f.numpy(), np.array(targets), 2, 2)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b))
+    assert rel(Pc.numpy(), g_ref) < 0.03
+    # group prototypes are compared as sets per class (cluster labels are arbitrary)
+    for c in range(2):
+        d = np.linalg.norm(Pg[c].numpy()[:, None] - l_ref[c][None], axis=-1)
+        assert min(d[0, 0] + d[1, 1], d[0, 1] + d[1, 0]) < 0.06 * np.linalg.norm(l_ref[c])
