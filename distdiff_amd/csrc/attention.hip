@@ -320,11 +320,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
   const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
 
+  // K/V tiles are register-staged one tile ahead like the forward (the global latency hides under the previous tile's MFMAs)
+  constexpr bool PREFETCH = (DPK <= 160);
+  TileRegs<KT, PREFETCH ? DPK : 32> kreg, vreg;
+  if (PREFETCH) {
+    tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
+    tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg, p.ldv, p.Nk, D, tid);
+  }
   for (int k0 = 0; k0 < p.Nk; k0 += KT) {
     __syncthreads();
-    stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
-    stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    if (PREFETCH) {
+      tile_store<KT, PREFETCH ? DPK : 32>(kreg, Ks, S, tid);
+      tile_store<KT, PREFETCH ? DPK : 32>(vreg, Vs, S, tid);
+    } else {
+      stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
+      stage_tile<KT, DPK>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
+    }
     __syncthreads();
+    if (PREFETCH && k0 + KT < p.Nk) {
+      tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg + (size_t)(k0 + KT) * p.ldk, p.ldk, p.Nk - k0 - KT, D, tid);
+      tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg + (size_t)(k0 + KT) * p.ldv, p.ldv, p.Nk - k0 - KT, D, tid);
+    }
     bf16x8 dsf[QT][NC];
     {
       f32x4 st[QT][NKT], dpt[QT][NKT];
@@ -432,31 +448,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const float* lseg = p.lse + ((size_t)b * p.H + h) * p.Nq;
   const float* delg = p.delta + ((size_t)b * p.H + h) * p.Nq;
 
-  for (int q0 = 0; q0 < p.Nq; q0 += QTL) {
-    __syncthreads();
-    stage_tile<QTL, DPK>(Qs, S, qg + (size_t)q0 * p.ldq, p.ldq, p.Nq - q0, D, tid);
-    stage_tile<QTL, DPK>(Os, S, og + (size_t)q0 * p.lddo, p.lddo, p.Nq - q0, D, tid);
+  // Q / dO tiles (and their lse / delta rows) are register-staged one tile ahead for the small head dims
+  constexpr bool PREFETCH = (DPK <= 160);
+  TileRegs<QTL, PREFETCH ? DPK : 32> qreg, oreg;
+  float lreg = INFINITY, dreg = 0.f;
+  auto load_rows = [&](int q0) {
     if (tid < QTL) {
       const bool v = q0 + tid < p.Nq;
-      ls[tid] = v ? lseg[q0 + tid] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
-      ls[QTL + tid] = v ? delg[q0 + tid] : 0.f;
+      lreg = v ? lseg[q0 + tid] * LOG2E : INFINITY;      // +inf -> P = 0 for padded query rows
+      dreg = v ? delg[q0 + tid] : 0.f;
     }
+  };
+  if (PREFETCH) {
+    tile_load<QTL, PREFETCH ? DPK : 32>(qreg, qg, p.ldq, p.Nq, D, tid);
+    tile_load<QTL, PREFETCH ? DPK : 32>(oreg, og, p.lddo, p.Nq, D, tid);
+    load_rows(0);
+  }
+  for (int q0 = 0; q0 < p.Nq; q0 += QTL) {
     __syncthreads();
+    if (PREFETCH) {
+      tile_store<QTL, PREFETCH ? DPK : 32>(qreg, Qs, S, tid);
+      tile_store<QTL, PREFETCH ? DPK : 32>(oreg, Os, S, tid);
+    } else {
+      stage_tile<QTL, DPK>(Qs, S, qg + (size_t)q0 * p.ldq, p.ldq, p.Nq - q0, D, tid);
+      stage_tile<QTL, DPK>(Os, S, og + (size_t)q0 * p.lddo, p.lddo, p.Nq - q0, D, tid);
+      load_rows(q0);
+    }
+    if (tid < QTL) { ls[tid] = lreg; ls[QTL + tid] = dreg; }
+    __syncthreads();
+    if (PREFETCH && q0 + QTL < p.Nq) {
+      tile_load<QTL, PREFETCH ? DPK : 32>(qreg, qg + (size_t)(q0 + QTL) * p.ldq, p.ldq, p.Nq - q0 - QTL, D, tid);
+      tile_load<QTL, PREFETCH ? DPK : 32>(oreg, og + (size_t)(q0 + QTL) * p.lddo, p.lddo, p.Nq - q0 - QTL, D, tid);
+      load_rows(q0 + QTL);
+    }
     bf16x8 pf[KTW][NC], dsf[KTW][NC];
     {
       f32x4 s[KTW][NQT], dp[KTW][NQT];
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
-#pragma unroll
-        for (int kt = 0; kt < KTW; ++kt) { s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // the first K slice accumulates onto a literal zero (an inline-constant C operand: no v_mov zeroing of 16 accumulators)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 qfr = lds_row_frag(Qs, qt * 16 + i16, S, g + 4 * ks);
           const bf16x8 ofr = lds_row_frag(Os, qt * 16 + i16, S, g + 4 * ks);
 #pragma unroll
           for (int kt = 0; kt < KTW; ++kt) {
-            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], s[kt][qt], 0, 0, 0);
-            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kt][ks], dp[kt][qt], 0, 0, 0);
+            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[kt][qt], 0, 0, 0);
+            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : dp[kt][qt], 0, 0, 0);
           }
         }
       }
