@@ -70,6 +70,15 @@ class AttnParams(C.Structure):
                 ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("delta", vp), ("accumulate_dq", C.c_int), ("causal", C.c_int)]
 
 
+class ConvF32Params(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("taptab", vp), ("y", vp), ("bias", vp), ("res", vp), ("mask", vp),
+                ("x_ld", C.c_int), ("y_ld", C.c_int), ("res_ld", C.c_int), ("mask_ld", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("stride", C.c_int),
+                ("shift", C.c_int), ("parity", C.c_int), ("cin", C.c_int), ("ntaps", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("groups", C.c_int), ("cpg_in", C.c_int), ("cpg_out", C.c_int), ("flags", C.c_int)]
+
+
 CF_BIAS, CF_RES, CF_RELU, CF_GEGLU, CF_OUT_F32, CF_MASK, CF_RES_F32, CF_GEGLU_RAW = 1, 2, 4, 8, 16, 32, 64, 128
 
 # every symbol declared in include/distdiff_hip_ops.h and include/distdiff_hip.h (checked by tests/test_abi.py)
@@ -77,7 +86,7 @@ OPS_SYMBOLS = [
     "dd_op_conv_gemm", "dd_op_groupnorm_fwd", "dd_op_groupnorm_bwd", "dd_op_groupnorm_scratch_bytes",
     "dd_op_layernorm_fwd", "dd_op_layernorm_bwd", "dd_op_attention_fwd", "dd_op_attention_bwd",
     "dd_op_attention_gemm_workspace", "dd_op_attention_gemm_fwd", "dd_op_attention_gemm_bwd",
-    "dd_pack_conv_weight", "dd_op_nchw_f32_to_nhwc_bf16", "dd_op_nhwc_to_nchw_f32", "dd_op_cfg_ddim",
+    "dd_pack_conv_weight", "dd_op_conv_f32", "dd_pack_conv_weight_f32", "dd_op_nchw_f32_to_nhwc_bf16", "dd_op_nhwc_to_nchw_f32", "dd_op_cfg_ddim",
     "dd_op_cfg_ddim_bwd", "dd_op_sumpool2x2", "dd_op_geglu_bwd", "dd_op_maxpool3x3s2", "dd_op_maxpool3x3s2_bwd",
     "dd_op_bicubic", "dd_op_bicubic_bwd", "dd_op_gap", "dd_op_energy", "dd_op_transform_update", "dd_op_affine",
 ]
@@ -85,7 +94,7 @@ ENGINE_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
     "dd_set_schedule", "dd_add_noise", "dd_denoise_step", "dd_transform_guidance", "dd_direct_guidance", "dd_decode",
     "dd_expand", "dd_image_to_u8", "dd_guide_encode", "dd_unet_forward", "dd_unet_vjp", "dd_decode_vjp", "dd_guide_vjp",
-    "dd_set_prompt", "dd_vae_encode", "dd_text_encode", "dd_debug_tensor", "dd_debug_num_tensors", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
+    "dd_set_prompt", "dd_vae_encode", "dd_text_encode", "dd_set_sample_weights", "dd_get_image_scores", "dd_debug_tensor", "dd_debug_num_tensors", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
 ]
 
 
@@ -101,6 +110,8 @@ def _declare(l):
     l.dd_op_attention_fwd.argtypes = [C.POINTER(AttnParams), vp]
     l.dd_op_attention_bwd.argtypes = [C.POINTER(AttnParams), vp]
     l.dd_pack_conv_weight.argtypes = [vp, i, i, i, i, i, i, i, vp, vp, vp]
+    l.dd_op_conv_f32.argtypes = [C.POINTER(ConvF32Params), vp]
+    l.dd_pack_conv_weight_f32.argtypes = [vp, i, i, i, i, i, i, i, vp, vp, vp]
     l.dd_op_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i, i, i, i, i, i, i, f, vp]
     l.dd_op_nhwc_to_nchw_f32.argtypes = [vp, i, vp, i, i, i, i, i, f, f, i, f, f, vp]
     l.dd_op_cfg_ddim.argtypes = [vp, i, vp, vp, vp, i, i, i, vp, vp]

@@ -352,13 +352,15 @@ __device__ float block_sum(float v, float* red) {
 // single block: loops over the batch so that the score accumulation order is fixed (deterministic)
 __global__ __launch_bounds__(256) void energy_kernel(const float* f, const float* Pc, const float* Pg, const int* targets, int B,
                                                      int D, int K, float gs, float ls, int use_c, int use_g, int normalize,
-                                                     float weight, float* score_out, float* gf) {
+                                                     float weight, const float* sample_w, float* score_out, float* image_scores,
+                                                     float* gf) {
   __shared__ float red[8];
   __shared__ float dots[64];
   float score = 0.f;
   for (int b = 0; b < B; ++b) {
     const float* fb = f + (size_t)b * D;
     const int y = targets[b];
+    const float wb = sample_w ? sample_w[b] : 1.f / B;   // the reference's mean over its batch group (:709, :716, :751, :758)
     float nrm = 1.f;
     if (normalize) {
       float s = 0.f;
@@ -392,10 +394,12 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* f, const float
       for (int d = threadIdx.x; d < D; d += blockDim.x) { const float t = fb[d] * inv - pg[d]; s += t * t; }
       dg = sqrtf(block_sum(s, red));
     }
-    score += (use_c ? gs * dc : 0.f) + (use_g ? ls * dg : 0.f);
+    const float Eb = (use_c ? gs * dc : 0.f) + (use_g ? ls * dg : 0.f);
+    score += wb * Eb;
+    if (image_scores && threadIdx.x == 0) image_scores[b] += weight * Eb;
     if (gf) {
       // gradient wrt fhat, then through the optional normalisation
-      const float wc = use_c ? weight * gs / (B * dc) : 0.f, wg = use_g ? weight * ls / (B * dg) : 0.f;
+      const float wc = use_c ? weight * gs * wb / dc : 0.f, wg = use_g ? weight * ls * wb / dg : 0.f;
       float dotp = 0.f;
       if (normalize) {
         float s = 0.f;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* f, const float
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) score_out[0] += weight * score / B;
+  if (threadIdx.x == 0) score_out[0] += weight * score;
 }
 
 __global__ void affine_kernel(const float* z, const float* e, const float* b, float* out, int BC, int HW) {
@@ -602,10 +606,11 @@ hipError_t launch_gap_bwd(const float* gf, bf16_t* dx, int ld, int B, int HW, in
   LAUNCH(gap_bwd_kernel, (size_t)B * HW * C, gf, dx, ld, B, HW, C, mask, mask_ld);
 }
 hipError_t launch_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K, float gs,
-                         float ls, int use_c, int use_g, int normalize, float weight, float* score_out, float* gf, hipStream_t s) {
+                         float ls, int use_c, int use_g, int normalize, float weight, const float* sample_w, float* score_out,
+                         float* image_scores, float* gf, hipStream_t s) {
   if (K > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(energy_kernel, dim3(1), dim3(256), 0, s, f, Pc, Pg, targets, B, D, K, gs, ls, use_c, use_g, normalize, weight,
-                     score_out, gf);
+                     sample_w, score_out, image_scores, gf);
   return hipGetLastError();
 }
 hipError_t launch_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, hipStream_t s) {

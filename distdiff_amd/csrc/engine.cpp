@@ -56,6 +56,9 @@ struct ConvW {
   int Cout = 0, Cin = 0, KH = 1, KW = 1, pad = 0;
   int pad_br = 0;              // extra zero rows/cols at the bottom/right only (AutoencoderKL encoder downsample: F.pad (0,1,0,1))
   bool geglu = false;
+  int groups = 1;              // grouped convolution (ResNeXt guide); fp32 programs only
+  bool f32 = false;            // fp32 packing for the guide program (guide_f32.hip): wf_* / sf / sb describe the fp32 matrices
+  float* wf_fwd = nullptr; float* wf_bwd = nullptr;
   PackedConv sf{}, sb{};
   bf16_t* w_fwd = nullptr; int* tap_fwd = nullptr;
   bf16_t* w_bwd = nullptr; int* tap_bwd = nullptr;
@@ -100,14 +103,15 @@ struct Program {
   size_t act_bytes = 0, grad_bytes = 0;
   size_t scratch_partial = 0, scratch_tmp = 0;  // shared scratch requirements (bytes)
   bool want_grad = false;
+  bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
 
-  int tensor(int B, int H, int W, int C, bool grad = true, bool f32 = false) {
+  int tensor(int B, int H, int W, int C, bool grad = true, bool f32_act = false) {
     Tn n;
-    n.B = B; n.H = H; n.W = W; n.rows = B * H * W; n.C = C; n.ld = rup(C, 8); n.f32 = f32;
+    n.B = B; n.H = H; n.W = W; n.rows = B * H * W; n.C = C; n.ld = f32 ? rup(C, 4) : rup(C, 8); n.f32 = f32_act || f32;
     n.grad = grad && want_grad;
     n.off = act_bytes;
-    act_bytes += rup_sz((size_t)n.rows * n.ld * (f32 ? 4 : 2), 256);
-    if (n.grad) { n.goff = grad_bytes; grad_bytes += rup_sz((size_t)n.rows * n.ld * 2, 256); }
+    act_bytes += rup_sz((size_t)n.rows * n.ld * (n.f32 ? 4 : 2), 256);
+    if (n.grad) { n.goff = grad_bytes; grad_bytes += rup_sz((size_t)n.rows * n.ld * (f32 ? 4 : 2), 256); }
     n.parent = (int)t.size();
     t.push_back(n);
     return (int)t.size() - 1;
@@ -164,6 +168,8 @@ struct Ctx {  // per-call execution context
 
 inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
 inline bf16_t* grad_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.grad + t.goff); }
+inline float* act_f32(const Ctx& c, const Tn& t) { return (float*)(c.act + t.off); }
+inline float* grad_f32(const Ctx& c, const Tn& t) { return (float*)(c.grad + t.goff); }
 
 }  // namespace
 
@@ -214,10 +220,19 @@ struct dd_engine {
   float* f32_tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B,4,L,L] fp32 temporaries
   float* img_tmp = nullptr;    // [B,3,8L,8L] fp32
   float* score_tmp = nullptr;
+  float* sample_w = nullptr; bool sample_w_set = false;   // per-image energy weights (dd_set_sample_weights); default 1/B
+  float* image_scores = nullptr;                         // per-image energies of the last guidance call
   size_t total_bytes = 0;
   double flops = 0;
   Profiler prof;
 
+  void dfree(void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < dev_allocs.size(); ++i)
+      if (dev_allocs[i] == p) { dev_allocs[i] = dev_allocs.back(); dev_allocs.pop_back(); break; }
+    hipFree(p);
+  }
+  std::vector<void*> sched_allocs;   // tables of the current schedule (replaced by the next dd_set_schedule)
   void* dmalloc(size_t bytes, bool zero = true) {
     void* p = nullptr;
     bytes = std::max<size_t>(bytes, 256);
@@ -241,6 +256,31 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // weight construction
 // ---------------------------------------------------------------------------------------------------
+// fp32 packing (guide program): w is [Cout][Cin/groups][KH][KW]
+ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, int groups,
+                     bool need_bwd) {
+  auto cw = std::make_unique<ConvW>();
+  cw->Cout = Cout; cw->Cin = Cin; cw->KH = KH; cw->KW = KW; cw->pad = pad; cw->groups = groups; cw->f32 = true;
+  for (int mode = 0; mode < (need_bwd ? 2 : 1); ++mode) {
+    PackedConv& sh = mode ? cw->sb : cw->sf;
+    sh = pack_conv_shape_f32(Cout, Cin, KH, KW, mode, groups);
+    std::vector<float> wp((size_t)sh.N * sh.K);
+    std::vector<int> tt(sh.ntaps);
+    pack_conv_weight_f32(w, Cout, Cin, KH, KW, pad, mode, groups, wp.data(), tt.data());
+    float* d = (float*)E->dmalloc(wp.size() * 4, false);
+    HIPCHK(hipMemcpy(d, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    int* t = (int*)E->dmalloc(tt.size() * 4, false);
+    HIPCHK(hipMemcpy(t, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+    if (mode) { cw->wf_bwd = d; cw->tap_bwd = t; } else { cw->wf_fwd = d; cw->tap_fwd = t; }
+  }
+  if (bias) {
+    cw->bias = (float*)E->dmalloc(Cout * 4, false);
+    HIPCHK(hipMemcpy(cw->bias, bias, Cout * 4, hipMemcpyHostToDevice));
+  }
+  E->convs.push_back(std::move(cw));
+  return E->convs.back().get();
+}
+
 ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, bool geglu,
                      bool need_bwd) {
   auto cw = std::make_unique<ConvW>();
@@ -301,21 +341,27 @@ ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<s
 }
 
 // conv (no bias) followed by eval-mode BatchNorm, folded: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)
-ConvW* make_conv_bn(dd_engine* E, const std::string& model, const std::string& conv, const std::string& bn, int pad, float eps) {
+// `cin_total` = channels of the input tensor: groups = cin_total / weight.shape[1] (ResNeXt, model_utils.py:56-63).  The guide
+// program is fp32 (guide_f32.hip).
+ConvW* make_conv_bn(dd_engine* E, const std::string& model, const std::string& conv, const std::string& bn, int pad, float eps,
+                    int cin_total) {
   const HostTensor& w = E->get(model, conv + ".weight");
   const HostTensor& g = E->get(model, bn + ".weight");
   const HostTensor& be = E->get(model, bn + ".bias");
   const HostTensor& mu = E->get(model, bn + ".running_mean");
   const HostTensor& var = E->get(model, bn + ".running_var");
-  const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3];
+  const int Cout = (int)w.shape[0], Cg = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3];
+  if (Cg < 1 || cin_total % Cg || Cout % (cin_total / Cg))
+    throw std::runtime_error("guide conv " + conv + ": weight shape does not divide the input channels (groups)");
+  const int groups = cin_total / Cg;
   std::vector<float> wf(w.data.size()), bf(Cout);
-  const size_t per = (size_t)Cin * KH * KW;
+  const size_t per = (size_t)Cg * KH * KW;
   for (int n = 0; n < Cout; ++n) {
     const float sc = g.data[n] / sqrtf(var.data[n] + eps);
     for (size_t i = 0; i < per; ++i) wf[n * per + i] = w.data[n * per + i] * sc;
     bf[n] = be.data[n] - mu.data[n] * sc;
   }
-  return make_conv_raw(E, wf.data(), bf.data(), Cout, Cin, KH, KW, pad, false, E->cfg.enable_grad != 0);
+  return make_conv_f32(E, wf.data(), bf.data(), Cout, cin_total, KH, KW, pad, groups, E->cfg.enable_grad != 0);
 }
 
 NormW* make_norm(dd_engine* E, const std::string& model, const std::string& prefix) {
@@ -351,7 +397,8 @@ struct Builder {
     op.out_f32 = out_f32; op.use_table = use_table;
     if (w->geglu && P.want_grad && keep_raw) op.raw = P.tensor(tx.B, Ho, Wo, w->Cout, false);
     const size_t M = (size_t)tx.B * Ho * Wo;
-    op.flops = 2.0 * M * w->Cout * w->Cin * w->KH * w->KW;
+    op.flops = 2.0 * M * w->Cout * (w->Cin / w->groups) * w->KH * w->KW;
+    if (w->f32) { P.ops.push_back(op); return y; }   // fp32 kernel: no split-K, no scratch
     const int split = conv_gemm_pick_split((int)M, w->sf.N, w->sf.K);
     P.scratch_partial = std::max(P.scratch_partial, (size_t)split * M * w->sf.N * 4);
     if (P.want_grad) {
@@ -470,11 +517,57 @@ void fill_conv(ConvGemmParams& p, const Ctx& c) {
   p.alpha = 1.f;
 }
 
+// fp32 programs (the guide network): conv forward / dgrad on guide_f32.hip
+void conv_f32_geometry(ConvF32Params& p, const ConvW* w, bool bwd) {
+  const PackedConv& sh = bwd ? w->sb : w->sf;
+  p.w = bwd ? w->wf_bwd : w->wf_fwd; p.taptab = bwd ? w->tap_bwd : w->tap_fwd;
+  p.cin = sh.cin; p.ntaps = sh.ntaps; p.N = sh.N; p.K = sh.K;
+  p.groups = w->groups;
+  const int gi = w->Cin / w->groups, go = w->Cout / w->groups;
+  p.cpg_in = bwd ? go : gi; p.cpg_out = bwd ? gi : go;
+}
+
+void run_conv_f32_fwd(const Program& P, const Op& op, const Ctx& c) {
+  const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+  const ConvW* w = op.cw;
+  ConvF32Params p; memset(&p, 0, sizeof p);
+  conv_f32_geometry(p, w, false);
+  p.x = act_f32(c, x); p.x_ld = x.ld; p.y = act_f32(c, y); p.y_ld = y.ld;
+  p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.M = y.rows;
+  if (w->bias) { p.flags |= CF_BIAS; p.bias = w->bias; }
+  if (op.res >= 0) { p.flags |= CF_RES; p.res = act_f32(c, P.t[op.res]); p.res_ld = P.t[op.res].ld; }
+  if (op.relu) p.flags |= CF_RELU;
+  HIPCHK(launch_conv_f32(p, c.s));
+}
+
+void run_conv_f32_bwd(const Program& P, const Op& op, const Ctx& c) {
+  const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+  const ConvW* w = op.cw;
+  float* gy = grad_f32(c, y);
+  // ReLU mask from the fp32 forward output (y > 0), then the residual fan-out, then the dgrad GEMM
+  if (op.relu) HIPCHK(launch_mask_f32(gy, y.ld, act_f32(c, y), y.ld, gy, y.ld, y.rows, rup(y.C, 4), c.s));
+  if (op.res >= 0 && P.t[op.res].grad) {
+    const Tn& r = P.t[op.res];
+    if (op.res_acc) HIPCHK(launch_add_f32(grad_f32(c, r), r.ld, gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
+    else HIPCHK(launch_copy_f32(gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
+  }
+  if (!x.grad) return;
+  ConvF32Params p; memset(&p, 0, sizeof p);
+  conv_f32_geometry(p, w, true);
+  p.x = gy; p.x_ld = y.ld;
+  p.B = y.B; p.H = y.H; p.W = y.W; p.Ho = x.H; p.Wo = x.W; p.M = x.rows; p.stride = 1;
+  if (op.stride == 2) { p.shift = 1; p.parity = 1; }
+  float* gx = grad_f32(c, x);
+  p.y = gx; p.y_ld = x.ld;
+  if (op.x_acc) { p.flags |= CF_RES; p.res = gx; p.res_ld = x.ld; }
+  HIPCHK(launch_conv_f32(p, c.s));
+}
+
 void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) {
   if (op_end < 0) op_end = (int)P.ops.size();
   for (int i = op_begin; i < op_end; ++i) {
     const Op& op = P.ops[i];
-    const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
+    const int fam = (op.kind == OP_CONV && !P.f32) ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
                     : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
     if (c.prof) {
       if (op.kind == OP_CONV) c.prof->begin(fam, op.flops, c.s, P.t[op.y].rows, op.cw->sf.N, op.cw->sf.K, 0);
@@ -483,6 +576,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
     }
     switch (op.kind) {
       case OP_CONV: {
+        if (P.f32) { run_conv_f32_fwd(P, op, c); if (c.flops) *c.flops += op.flops; break; }
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         ConvGemmParams p; fill_conv(p, c);
         const ConvW* w = op.cw;
@@ -545,7 +639,8 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
       } break;
       case OP_MAXPOOL: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
-        HIPCHK(launch_maxpool3x3s2(act_ptr(c, x), act_ptr(c, y), x.B, x.H, x.W, x.C, c.s));
+        if (P.f32) HIPCHK(launch_maxpool3x3s2_f32(act_f32(c, x), act_f32(c, y), x.B, x.H, x.W, x.ld, c.s));
+        else HIPCHK(launch_maxpool3x3s2(act_ptr(c, x), act_ptr(c, y), x.B, x.H, x.W, x.C, c.s));
       } break;
       case OP_ACT: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
@@ -560,7 +655,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
 void run_bwd(const Program& P, const Ctx& c) {
   for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
     const Op& op = P.ops[i];
-    const int fam = op.kind == OP_CONV ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
+    const int fam = (op.kind == OP_CONV && !P.f32) ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
                     : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
     if (c.prof) {
       if (op.kind == OP_CONV) c.prof->begin(fam, op.flops, c.s, P.t[op.x].rows << (2 * op.up), op.cw->sb.N, op.cw->sb.K, 1);
@@ -572,6 +667,7 @@ void run_bwd(const Program& P, const Ctx& c) {
       case OP_CONV: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         if (!x.grad && !(op.res >= 0 && P.t[op.res].grad)) break;
+        if (P.f32) { run_conv_f32_bwd(P, op, c); if (x.grad && c.flops) *c.flops += op.flops; break; }
         bf16_t* gy = grad_ptr(c, y);
         const ConvW* w = op.cw;
         if (op.relu) HIPCHK(launch_mask_bf16(gy, y.ld, act_ptr(c, y), y.ld, gy, y.ld, y.rows, y.C, c.s));
@@ -667,7 +763,8 @@ void run_bwd(const Program& P, const Ctx& c) {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         if (!x.grad) break;
         if (op.x_acc) throw std::runtime_error("maxpool backward accumulate unsupported");
-        HIPCHK(launch_maxpool3x3s2_bwd(act_ptr(c, x), grad_ptr(c, y), grad_ptr(c, x), x.B, x.H, x.W, x.C, c.s));
+        if (P.f32) HIPCHK(launch_maxpool3x3s2_bwd_f32(act_f32(c, x), grad_f32(c, y), grad_f32(c, x), x.B, x.H, x.W, x.ld, c.s));
+        else HIPCHK(launch_maxpool3x3s2_bwd(act_ptr(c, x), grad_ptr(c, y), grad_ptr(c, x), x.B, x.H, x.W, x.C, c.s));
       } break;
       case OP_GAP: case OP_ACT: break;
     }
@@ -811,7 +908,8 @@ void build_vae(dd_engine* E) {
     }
   }
   h = b.gn(h, make_norm(E, m, "decoder.conv_norm_out"), G, eps, 1);
-  E->vae_out = b.conv(h, make_conv(E, m, "decoder.conv_out", 1));
+  // the image leaves the decoder in fp32 (no bf16 rounding in front of the guide's ReLU masks or the uint8 quantisation)
+  E->vae_out = b.conv(h, make_conv(E, m, "decoder.conv_out", 1), 1, 0, -1, 0, /*out_f32=*/1);
   if (P.want_grad) plan_backward(P);
 }
 
@@ -904,25 +1002,28 @@ void build_guide(dd_engine* E) {
   const dd_config& c = E->cfg;
   Program& P = E->guide;
   P.want_grad = c.enable_grad != 0;
+  P.f32 = true;   // exact fp32 forward, masks and VJP (guide_f32.hip): the energy gradient goes through this network's ReLU masks
   Builder b(E, P);
   const std::string m = "guide";
   const int B = c.max_batch, S = c.guide_input_size;
   const float eps = c.guide_bn_eps;
   E->guide_in = P.tensor(B, S, S, 3);
-  int h = b.conv(E->guide_in, make_conv_bn(E, m, "conv1", "bn1", 3, eps), 2, 0, -1, 1);
+  // timm ResNet family (model_utils.py:47-79): widths, groups (ResNeXt) and the bottleneck width (Wide-ResNet) come from the
+  // weight shapes of the state dict
+  int h = b.conv(E->guide_in, make_conv_bn(E, m, "conv1", "bn1", 3, eps, 3), 2, 0, -1, 1);
   h = b.maxpool(h);
-  char buf[128], bn[128];
+  char buf[128];
   for (int li = 0; li < c.guide_stages; ++li)
     for (int bi = 0; bi < c.guide_blocks[li]; ++bi) {
       const int stride = (bi == 0 && li > 0) ? 2 : 1;
       snprintf(buf, sizeof buf, "layer%d.%d", li + 1, bi);
       const std::string p = buf;
-      int o = b.conv(h, make_conv_bn(E, m, p + ".conv1", p + ".bn1", 0, eps), 1, 0, -1, 1);
-      o = b.conv(o, make_conv_bn(E, m, p + ".conv2", p + ".bn2", 1, eps), stride, 0, -1, 1);
+      int o = b.conv(h, make_conv_bn(E, m, p + ".conv1", p + ".bn1", 0, eps, P.t[h].C), 1, 0, -1, 1);
+      o = b.conv(o, make_conv_bn(E, m, p + ".conv2", p + ".bn2", 1, eps, P.t[o].C), stride, 0, -1, 1);
       int sc = h;
-      if (E->has(m, p + ".downsample.0.weight")) sc = b.conv(h, make_conv_bn(E, m, p + ".downsample.0", p + ".downsample.1", 0, eps), stride);
-      h = b.conv(o, make_conv_bn(E, m, p + ".conv3", p + ".bn3", 0, eps), 1, 0, sc, 1);
-      (void)bn;
+      if (E->has(m, p + ".downsample.0.weight"))
+        sc = b.conv(h, make_conv_bn(E, m, p + ".downsample.0", p + ".downsample.1", 0, eps, P.t[h].C), stride);
+      h = b.conv(o, make_conv_bn(E, m, p + ".conv3", p + ".bn3", 0, eps, P.t[o].C), 1, 0, sc, 1);
     }
   E->guide_feat = h;
   if (P.want_grad) plan_backward(P);
@@ -977,10 +1078,11 @@ void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
   Ctx vc = r.ctx(E->vae, E->inst[k].vae);
   const Tn& img = E->vae.t[E->vae_out];
   const Tn& gin = E->guide.t[E->guide_in];
-  HIPCHK(launch_bicubic(act_ptr(vc, img), img.ld, act_ptr(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
+  // the decoder's conv_out stores the image in fp32: image, bicubic resize and the whole guide stay fp32
+  HIPCHK(launch_bicubic_f32(act_f32(vc, img), img.ld, act_f32(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
   run_fwd(E->guide, gc);
   const Tn& f = E->guide.t[E->guide_feat];
-  HIPCHK(launch_gap(act_ptr(gc, f), f.ld, E->inst[k].feat, c.max_batch, f.H * f.W, f.C, s));
+  HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, E->inst[k].feat, nullptr, c.max_batch, f.H * f.W, f.C, 0, s));
 }
 
 // reverse of guide_fwd_from_image + vae_fwd: gfeat -> g_x0 (fp32 NCHW)
@@ -991,12 +1093,12 @@ void guide_vae_bwd(dd_engine* E, int k, float* g_x0, hipStream_t s) {
   Ctx vc = r.ctx(E->vae, E->inst[k].vae);
   const Tn& f = E->guide.t[E->guide_feat];
   // GAP^T; the ReLU mask of the last bottleneck is applied by that conv op's backward
-  HIPCHK(launch_gap_bwd(E->inst[k].gfeat, grad_ptr(gc, f), f.ld, c.max_batch, f.H * f.W, f.C, nullptr, 0, s));
+  HIPCHK(launch_gap_bwd_f32(E->inst[k].gfeat, grad_f32(gc, f), f.ld, c.max_batch, f.H * f.W, f.C, nullptr, s));
   run_bwd(E->guide, gc);
   const Tn& gin = E->guide.t[E->guide_in];
   const Tn& img = E->vae.t[E->vae_out];
-  // the guide and VAE gradient regions are disjoint parts of the shared gradient slab (see finalize)
-  HIPCHK(launch_bicubic_bwd(grad_ptr(gc, gin), gin.ld, grad_ptr(vc, img), img.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, s));
+  // the guide (fp32) and VAE (bf16) gradient regions are disjoint parts of the shared gradient slab (see finalize)
+  HIPCHK(launch_bicubic_bwd_f32(grad_f32(gc, gin), gin.ld, grad_ptr(vc, img), 1, img.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, s));
   run_bwd(E->vae, vc);
   const Tn& vin = E->vae.t[E->vae_in];
   HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(vc, vin), 0, g_x0, c.max_batch, c.vae_latent_channels, c.latent_size, c.latent_size, vin.ld,
@@ -1016,7 +1118,7 @@ void guided_forward(dd_engine* E, int k, const float* z_in, int step_index, cons
   vae_fwd(E, k, I.x0, s);
   guide_fwd_from_image(E, k, s);
   HIPCHK(launch_energy(I.feat, E->Pc, E->Pg, targets, c.max_batch, E->pD, E->pK, E->sp.gs, E->sp.ls, E->sp.use_global, E->sp.use_local,
-                       normalize, weight, score, I.gfeat, s));
+                       normalize, weight, E->sample_w_set ? E->sample_w : nullptr, score, E->image_scores, I.gfeat, s));
 }
 
 // reverse of guided_forward: given g_znext (may be null) returns g_z (fp32 NCHW) in g_z_out
@@ -1141,6 +1243,8 @@ int dd_finalize_weights(dd_engine* E) {
     for (auto& f : E->f32_tmp) f = (float*)E->dmalloc(zbytes);
     E->img_tmp = (float*)E->dmalloc((size_t)B * 3 * 64 * L * L * 4);
     E->score_tmp = (float*)E->dmalloc(256);
+    E->sample_w = (float*)E->dmalloc((size_t)B * 4);
+    E->image_scores = (float*)E->dmalloc((size_t)B * 4);
     // cross-attention K/V buffers
     E->ctx_bf16 = (bf16_t*)E->dmalloc((size_t)2 * B * c.text_len * rup(c.unet_cross_dim, 8) * 2);
     for (auto& sl : E->cross_slots) {
@@ -1161,6 +1265,9 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
     const dd_config& c = E->cfg;
     E->timesteps.assign(timesteps, timesteps + n);
     E->sp = *sp;
+    HIPCHK(hipDeviceSynchronize());
+    for (void* q : E->sched_allocs) E->dfree(q);
+    E->sched_allocs.clear();
     std::vector<float> coef((size_t)n * 8, 0.f);
     const int ratio = num_train / n;
     for (int i = 0; i < n; ++i) {
@@ -1171,6 +1278,7 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
       q[0] = sp->guidance_scale; q[1] = (float)sqrt(a); q[2] = (float)sqrt(1 - a); q[3] = (float)sqrt(ap); q[4] = (float)sqrt(1 - ap);
     }
     E->coef_table = (float*)E->dmalloc(coef.size() * 4, false);
+    E->sched_allocs.push_back(E->coef_table);
     HIPCHK(hipMemcpy(E->coef_table, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
     // sinusoidal timestep embedding (diffusers Timesteps: flip_sin_to_cos, freq_shift) on host, MLP + projections on GPU (fp32)
     const int C0 = c.unet_block_out_channels[0], half = C0 / 2, TE = C0 * 4;
@@ -1187,10 +1295,12 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
     HIPCHK(hipMemcpy(d_sin, sinus.data(), sinus.size() * 4, hipMemcpyHostToDevice));
     float* d_h1 = (float*)E->dmalloc((size_t)n * TE * 4, false);
     float* d_emb = (float*)E->dmalloc((size_t)n * TE * 4, false);
+    E->sched_allocs.push_back(d_sin); E->sched_allocs.push_back(d_h1); E->sched_allocs.push_back(d_emb);
     HIPCHK(launch_linear_f32(d_sin, E->temb_w1, E->temb_b1, d_h1, n, TE, C0, 0, nullptr));
     HIPCHK(launch_linear_f32(d_h1, E->temb_w2, E->temb_b2, d_emb, n, TE, TE, 1, nullptr));
     for (ConvW* cw : E->temb_convs) {
       cw->bias_table = (float*)E->dmalloc((size_t)n * cw->Cout * 4, false);
+      E->sched_allocs.push_back(cw->bias_table);
       HIPCHK(launch_linear_f32(d_emb, cw->temb_w, cw->temb_b, cw->bias_table, n, cw->Cout, TE, 1, nullptr));
       // + conv1.bias
       HIPCHK(hipDeviceSynchronize());
@@ -1208,6 +1318,8 @@ int dd_set_prototypes(dd_engine* E, const float* Pc, const float* Pg, int C, int
   if (!E || C < 1 || D < 1) return DD_ERR_ARG;
   DD_TRY(E, {
     E->pC = C; E->pK = K; E->pD = D;
+    HIPCHK(hipDeviceSynchronize());
+    E->dfree(E->Pc); E->dfree(E->Pg);
     E->Pc = nullptr; E->Pg = nullptr;
     if (Pc) { E->Pc = (float*)E->dmalloc((size_t)C * D * 4, false); HIPCHK(hipMemcpy(E->Pc, Pc, (size_t)C * D * 4, hipMemcpyHostToDevice)); }
     if (Pg) { E->Pg = (float*)E->dmalloc((size_t)C * K * D * 4, false); HIPCHK(hipMemcpy(E->Pg, Pg, (size_t)C * K * D * 4, hipMemcpyHostToDevice)); }
@@ -1285,7 +1397,7 @@ int dd_decode(dd_engine* E, const float* z, float* image_out, int denormalize, i
     hipStream_t s = (hipStream_t)stream;
     vae_fwd(E, 0, z, s);
     const Tn& img = E->vae.t[E->vae_out];
-    HIPCHK(launch_nhwc_to_nchw_f32(E->inst[0].vae + img.off, 0, image_out, B, c.vae_out_channels, img.H, img.W, img.ld,
+    HIPCHK(launch_nhwc_to_nchw_f32(E->inst[0].vae + img.off, 1, image_out, B, c.vae_out_channels, img.H, img.W, img.ld,
                                    denormalize ? 0.5f : 1.f, denormalize ? 0.5f : 0.f, denormalize, 0.f, 1.f, s));
   });
 }
@@ -1340,10 +1452,10 @@ int dd_guide_encode(dd_engine* E, const float* images, float* feats, int B, void
     Run r{E, s, B};
     Ctx gc = r.ctx(E->guide, E->inst[0].guide);
     const Tn& gin = E->guide.t[E->guide_in];
-    HIPCHK(launch_nchw_f32_to_nhwc_bf16(images, act_ptr(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, 0, 1.f, s));
+    HIPCHK(launch_nchw_to_nhwc_f32(images, act_f32(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, s));
     run_fwd(E->guide, gc);
     const Tn& f = E->guide.t[E->guide_feat];
-    HIPCHK(launch_gap(act_ptr(gc, f), f.ld, feats, B, f.H * f.W, f.C, s));
+    HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, feats, nullptr, B, f.H * f.W, f.C, 0, s));
   });
 }
 
@@ -1361,6 +1473,7 @@ int dd_transform_guidance(dd_engine* E, const float* z, const int* targets, cons
     const int BC = B * c.unet_in_channels, HW = c.latent_size * c.latent_size;
     float* score = score_out ? score_out : E->score_tmp;
     HIPCHK(hipMemsetAsync(score, 0, sizeof(float), s));
+    HIPCHK(hipMemsetAsync(E->image_scores, 0, (size_t)B * sizeof(float), s));
     // z0 = z*(1+e)+b  (generate_data.py:696)
     HIPCHK(launch_affine(z, ch_e, ch_b, E->inst[0].z_in, BC, HW, s));
     const float weight = 1.f / (float)E->sp.guidance_period;   // score / args.guidance_period (:719)
@@ -1395,6 +1508,7 @@ int dd_direct_guidance(dd_engine* E, const float* z, const int* targets, int ste
     const size_t n = (size_t)B * c.unet_in_channels * c.latent_size * c.latent_size;
     float* score = score_out ? score_out : E->score_tmp;
     HIPCHK(hipMemsetAsync(score, 0, sizeof(float), s));
+    HIPCHK(hipMemsetAsync(E->image_scores, 0, (size_t)B * sizeof(float), s));
     HIPCHK(hipMemcpyAsync(E->inst[0].z_in, z, n * 4, hipMemcpyDeviceToDevice, s));
     guided_forward(E, 0, E->inst[0].z_in, step_index, targets, 1, 1.f, score, s);
     float* g_z = E->f32_tmp[0];
@@ -1435,6 +1549,26 @@ int dd_expand(dd_engine* E, const dd_expand_args* a, void* stream) {
   } catch (const std::exception& ex) { E->err = ex.what(); return DD_ERR_HIP; }
   if (a->image_out) return dd_decode(E, cur, a->image_out, 1, a->B, stream);
   return DD_OK;
+}
+
+int dd_set_sample_weights(dd_engine* E, const float* w_host, int B) {
+  if (!E) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    E->sample_w_set = w_host != nullptr;
+    if (w_host) {
+      HIPCHK(hipDeviceSynchronize());   // a previous guidance call may still be reading the weights
+      HIPCHK(hipMemcpy(E->sample_w, w_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice));
+    }
+  });
+}
+
+int dd_get_image_scores(dd_engine* E, float* scores_out, int B, void* stream) {
+  if (!E || !scores_out) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    HIPCHK(hipMemcpyAsync(scores_out, E->image_scores, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  });
 }
 
 // ---- per-module VJP diagnostics (parity tests of the hand-derived reverse programs against torch.autograd) ----
@@ -1488,12 +1622,12 @@ int dd_guide_vjp(dd_engine* E, const float* images, const float* g_feats, float*
     Run r{E, s, B};
     Ctx gc = r.ctx(E->guide, E->inst[0].guide);
     const Tn& gin = E->guide.t[E->guide_in];
-    HIPCHK(launch_nchw_f32_to_nhwc_bf16(images, act_ptr(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, 0, 1.f, s));
+    HIPCHK(launch_nchw_to_nhwc_f32(images, act_f32(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, s));
     run_fwd(E->guide, gc);
     const Tn& f = E->guide.t[E->guide_feat];
-    HIPCHK(launch_gap_bwd(g_feats, grad_ptr(gc, f), f.ld, B, f.H * f.W, f.C, nullptr, 0, s));
+    HIPCHK(launch_gap_bwd_f32(g_feats, grad_f32(gc, f), f.ld, B, f.H * f.W, f.C, nullptr, s));
     run_bwd(E->guide, gc);
-    HIPCHK(launch_nhwc_to_nchw_f32(grad_ptr(gc, gin), 0, g_images_out, B, 3, gin.H, gin.W, gin.ld, 1.f, 0.f, 0, 0.f, 0.f, s));
+    HIPCHK(launch_nhwc_to_nchw_f32(grad_f32(gc, gin), 1, g_images_out, B, 3, gin.H, gin.W, gin.ld, 1.f, 0.f, 0, 0.f, 0.f, s));
   });
 }
 
@@ -1536,7 +1670,7 @@ int dd_debug_tensor(dd_engine* E, int prog, int idx, int want_grad, float* host_
     HIPCHK(hipDeviceSynchronize());
     char* base = want_grad ? E->grad_slab + t.goff : (prog == 0 ? E->inst[0].unet : prog == 1 ? E->inst[0].vae : E->inst[0].guide) + t.off;
     const size_t n = (size_t)t.rows * t.ld;
-    if (t.f32 && !want_grad) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
+    if ((t.f32 && !want_grad) || (want_grad && P.f32)) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
     else {
       std::vector<bf16_t> tmp(n);
       // views share rows with their parent: copy row by row

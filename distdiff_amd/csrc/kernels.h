@@ -172,10 +172,13 @@ hipError_t launch_gap_bwd(const float* gf, bf16_t* dx, int ld, int B, int HW, in
                           hipStream_t s);
 // energy (generate_data.py:707-717 / 747-759) and its gradient wrt f.
 //   f [B,D] fp32, Pc [Ccls,D], Pg [Ccls,K,D], targets [B] int32. normalize: direct-guidance L2-normalise first.
-//   score_out[0] += weight * (gs*mean||f-pc|| + ls*mean||f-pg*||);  gf [B,D] = weight * dE/df
+//   E_i = gs*||f_i-pc|| + ls*||f_i-pg*||;  score_out[0] += weight * sum_i w_i E_i;  gf [i,:] = weight * w_i * dE_i/df_i
+//   w_i = sample_w[i] (device [B]) or 1/B when null: the reference's `.mean()` runs over its train_batch_size group
+//   (:709-719, :750-760), which the caller expresses as w_i = 1/|group of i| when it packs several groups into one engine batch.
+//   image_scores (device [B], may be null): image_scores[i] += weight * E_i.
 hipError_t launch_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K,
-                         float gs, float ls, int use_c, int use_g, int normalize, float weight, float* score_out,
-                         float* gf, hipStream_t s);
+                         float gs, float ls, int use_c, int use_g, int normalize, float weight, const float* sample_w,
+                         float* score_out, float* image_scores, float* gf, hipStream_t s);
 // transform guidance update (generate_data.py:696, 721-728): per (b,c): ge = sum_hw g*z, gb = sum_hw g;
 //   e -= rho*ge, b -= rho*gb ; z_out = clamp(z*(1+e)+b, z-c, z+c) (lower bound first)
 hipError_t launch_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, hipStream_t s);
@@ -202,6 +205,41 @@ hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, f
 hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s);
 
 // ----------------------------------------------------------------------------------------------
+// The guide network in exact fp32 (guide_f32.hip): implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 and the fp32
+// forms of the guide's side kernels.  Same tap-table / stride / dilated-gather conventions as ConvGemmParams.
+// ----------------------------------------------------------------------------------------------
+struct ConvF32Params {
+  const float* x;       // input activations, NHWC fp32, row stride x_ld (multiple of 4)
+  const float* w;       // packed weights [N][K] fp32, k = (tap, cin), K % 16 == 0 (zero padded)
+  const int* taptab;
+  float* y;             // output fp32, row stride y_ld
+  const float* bias;    // [N] or null
+  const float* res;     // residual (CF_RES); may alias y (accumulating dgrad)
+  const float* mask;    // CF_MASK: multiply by (mask[m, n] > 0)
+  int x_ld, y_ld, res_ld, mask_ld;
+  int B, H, W, Ho, Wo, stride, shift, parity;
+  int cin, ntaps;       // channels per tap (multiple of 4; of 16 when groups > 1), taps
+  int M, N, K;
+  int groups, cpg_in, cpg_out;   // groups > 1: output column n reads K-channels [g*cpg_in, (g+1)*cpg_in), g = n / cpg_out
+  int flags;            // CF_BIAS | CF_RES | CF_RELU | CF_MASK
+};
+hipError_t launch_conv_f32(const ConvF32Params& p, hipStream_t s);
+hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int M, int C, hipStream_t s);
+hipError_t launch_copy_f32(const float* a, int lda, float* y, int ldy, int M, int C, hipStream_t s);
+hipError_t launch_mask_f32(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, hipStream_t s);
+hipError_t launch_maxpool3x3s2_f32(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t s);
+// src fp32 NHWC [B,Hs,Ws,ld_s] -> dst fp32 [B,Hd,Wd,ld_d]; the transpose writes bf16 rows (dsrc_bf16) or fp32
+hipError_t launch_bicubic_f32(const float* src, int ld_s, float* dst, int ld_d, int B, int Hs, int Ws, int Hd, int Wd, int C, int Cpad,
+                              hipStream_t s);
+hipError_t launch_bicubic_bwd_f32(const float* ddst, int ld_d, void* dsrc, int dsrc_bf16, int ld_s, int B, int Hs, int Ws, int Hd, int Wd,
+                                  int C, hipStream_t s);
+// global average (or max, model_utils.py:34-35) pool of fp32 rows -> f [B, C]; argmax [B, C] only for the max form
+hipError_t launch_gap_f32(const float* x, int ld, float* f, int* argmax, int B, int HW, int C, int use_max, hipStream_t s);
+hipError_t launch_gap_bwd_f32(const float* gf, float* dx, int ld, int B, int HW, int C, const int* argmax, hipStream_t s);
+hipError_t launch_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, hipStream_t s);
+
+// ----------------------------------------------------------------------------------------------
 // host-side weight packing (weights.cpp)
 // ----------------------------------------------------------------------------------------------
 struct PackedConv {
@@ -212,6 +250,10 @@ struct PackedConv {
 // geglu: the Cout dimension is permuted into 32-wide (16 hidden | 16 gate) groups (see CF_GEGLU)
 PackedConv pack_conv_shape(int Cout, int Cin, int KH, int KW, int mode);
 void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu, bf16_t* wp, int* taptab);
+// fp32 packing for the guide network (guide_f32.hip): cin padded to 4 (16 when groups > 1), K padded to 16, k = (tap, cin);
+// w is [Cout][Cin/groups][KH][KW] (torch grouped-conv layout), packed as the dense block-diagonal matrix
+PackedConv pack_conv_shape_f32(int Cout, int Cin, int KH, int KW, int mode, int groups);
+void pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int groups, float* wp, int* taptab);
 int geglu_perm(int packed_index, int F);  // packed column -> original row of the [2F] projection
 bf16_t host_f2bf(float f);
 float host_bf2f(bf16_t v);

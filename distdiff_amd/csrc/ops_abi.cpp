@@ -20,6 +20,14 @@ int dd_op_attention_gemm_bwd(const AttnParams* p, void* ws, const int* tap1x1, f
   return (int)launch_attention_gemm_bwd(*p, ws, tap1x1, partial, cap, S(st));
 }
 
+int dd_op_conv_f32(const ConvF32Params* p, void* st) { return (int)launch_conv_f32(*p, S(st)); }
+int dd_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int groups, float* wp, int* taptab,
+                            int* out4) {
+  const PackedConv s = pack_conv_shape_f32(Cout, Cin, KH, KW, mode, groups);
+  if (out4) { out4[0] = s.N; out4[1] = s.K; out4[2] = s.cin; out4[3] = s.ntaps; }
+  if (wp) pack_conv_weight_f32(w, Cout, Cin, KH, KW, pad, mode, groups, wp, taptab);
+  return 0;
+}
 int dd_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu, uint16_t* wp,
                         int* taptab, int* out4) {
   const PackedConv s = pack_conv_shape(Cout, Cin, KH, KW, mode);
@@ -67,7 +75,7 @@ int dd_op_bicubic_bwd(const uint16_t* ddst, int ld_d, uint16_t* dsrc, int ld_s, 
 int dd_op_gap(const uint16_t* x, int ld, float* f, int B, int HW, int C, void* st) { return (int)launch_gap(x, ld, f, B, HW, C, S(st)); }
 int dd_op_energy(const float* f, const float* Pc, const float* Pg, const int* targets, int B, int D, int K, float gs, float ls,
                  int use_c, int use_g, int normalize, float weight, float* score_out, float* gf, void* st) {
-  return (int)launch_energy(f, Pc, Pg, targets, B, D, K, gs, ls, use_c, use_g, normalize, weight, score_out, gf, S(st));
+  return (int)launch_energy(f, Pc, Pg, targets, B, D, K, gs, ls, use_c, use_g, normalize, weight, nullptr, score_out, nullptr, gf, S(st));
 }
 int dd_op_transform_update(const float* z, const float* g, const float* e, const float* b, float* z_out, int BC, int HW, float rho,
                            float c, void* st) {

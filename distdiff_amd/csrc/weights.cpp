@@ -58,3 +58,37 @@ void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int pad
       }
   }
 }
+
+PackedConv pack_conv_shape_f32(int Cout, int Cin, int KH, int KW, int mode, int groups) {
+  PackedConv s;
+  const int cin = mode == 0 ? Cin : Cout;
+  const int al = groups > 1 ? 16 : 4;
+  s.N = mode == 0 ? Cout : Cin;
+  s.cin = (cin + al - 1) / al * al;
+  s.ntaps = KH * KW;
+  s.K = (s.ntaps * s.cin + 15) / 16 * 16;
+  return s;
+}
+
+void pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int groups, float* wp, int* taptab) {
+  const PackedConv s = pack_conv_shape_f32(Cout, Cin, KH, KW, mode, groups);
+  memset(wp, 0, (size_t)s.N * s.K * sizeof(float));
+  const int nt = KH * KW;
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx) {
+      const int dy = mode == 0 ? ky - pad : pad - ky, dx = mode == 0 ? kx - pad : pad - kx;
+      taptab[ky * KW + kx] = ((dy + 32) << 6) | (dx + 32);
+    }
+  const int cpg_in = Cin / groups, cpg_out = Cout / groups;
+  for (int n = 0; n < Cout; ++n) {
+    const int g = n / cpg_out;
+    for (int ci = 0; ci < cpg_in; ++ci) {
+      const int c = g * cpg_in + ci;
+      for (int t = 0; t < nt; ++t) {
+        const float v = w[((size_t)n * cpg_in + ci) * nt + t];
+        if (mode == 0) wp[(size_t)n * s.K + (size_t)t * s.cin + c] = v;
+        else wp[(size_t)c * s.K + (size_t)t * s.cin + n] = v;
+      }
+    }
+  }
+}

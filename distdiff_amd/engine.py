@@ -67,6 +67,8 @@ def _declare(l):
     l.dd_vae_encode.argtypes = [vp, vp, vp, vp, vp, i, vp]
     l.dd_text_encode.argtypes = [vp, vp, vp, i, vp]
     l.dd_image_to_u8.argtypes = [vp, vp, vp, i, vp]
+    l.dd_set_sample_weights.argtypes = [vp, vp, i]
+    l.dd_get_image_scores.argtypes = [vp, vp, i, vp]
     l.dd_unet_forward.argtypes = [vp, vp, i, vp, i, vp]
     l.dd_unet_vjp.argtypes = [vp, vp, i, vp, vp, i, vp]
     l.dd_decode_vjp.argtypes = [vp, vp, vp, vp, i, vp]
@@ -184,6 +186,22 @@ class Engine:
         assert e.shape[0] == 2 * self.B
         self._chk(self.L.dd_set_prompt(self._h, _p(e), self.B, _stream()), "dd_set_prompt")
         self._keep = [e]
+
+    def set_sample_weights(self, w):
+        """w[i] = 1 / |reference batch of image i| (the `.mean()` of generate_data.py:709-719, 750-760 runs over train_batch_size
+        images), 0 for padding rows; None restores the default 1/B."""
+        if w is None:
+            self._chk(self.L.dd_set_sample_weights(self._h, vp(0), self.B), "dd_set_sample_weights")
+            return
+        a = torch.as_tensor(w, dtype=torch.float32).contiguous().cpu()
+        assert a.numel() == self.B
+        self._chk(self.L.dd_set_sample_weights(self._h, vp(a.data_ptr()), self.B), "dd_set_sample_weights")
+
+    def image_scores(self):
+        """Per-image energies of the most recent guidance call (device [B])."""
+        out = torch.empty(self.B, device=self.device, dtype=torch.float32)
+        self._chk(self.L.dd_get_image_scores(self._h, _p(out), self.B, _stream()), "dd_get_image_scores")
+        return out
 
     # ---- stage before the loop (SURVEY.md 8f-2; dataloader.py:633-661, 750-811) ------------------
     def vae_encode(self, images, noise=None, return_moments=False):

@@ -10,7 +10,14 @@ loop (:1130-1236) executed by the MI355X engine (libdistdiff_hip.so) instead of 
 
 Superset over the reference (documented, defaults reproduce it): `--steps` and `--resolution` are honoured
 (the reference parses but ignores them); `--synthetic N` runs on N seeded synthetic images with
-synthetic weights (no checkpoints / datasets are needed; used by tests and benchmarks).
+synthetic weights (no checkpoints / datasets are needed; used by tests and benchmarks); `--gpus N` replaces the reference's
+per-GPU shell fan-out (`--split k --total_split N` per process, scripts/exps/expand_diff.sh:19-24): one launcher spawns N ranks,
+rank 0 loads and packs the weights once and broadcasts the packed device buffers over RCCL/xGMI (distdiff_amd/launcher.py).
+`--center_crop` is accepted and ignored like the reference, which hard-codes `center_crop=False` for SDDataset
+(generate_data.py:1001).  `--offset_noise` (:1164-1168) and `--language_enhance` (dataloader.py:769-778, 832-833) are implemented.
+Random streams: `e`/`b` of transform_guidance come from the CPU global generator in the reference's order (one draw of each per
+reference batch, :692-694); the initial noise comes from a dedicated generator seeded with --seed (the reference draws it from the
+CUDA global generator, whose stream no other device reproduces) -- see INTEGRATION.md.
 The stage before the loop runs on the engine too: image latents come from the reference's cache
 `save/vae_embedding/<dataset>/<model>/image_latents.pt` when it exists and are otherwise produced by the HIP VAE encoder and
 written to that path in the same format (dataloader.py:788-811); class prompts go through the Hugging Face tokenizer of the
@@ -41,7 +48,7 @@ _IGNORED_VALUE_FLAGS = ["--revision", "--variant", "--dataset_name", "--dataset_
 _IGNORED_BOOL_FLAGS = ["--center_crop", "--random_flip", "--with_prior_preservation", "--train_text_encoder", "--gradient_checkpointing",
                        "--scale_lr", "--use_8bit_adam", "--allow_tf32", "--enable_xformers_memory_efficient_attention",
                        "--set_grads_to_none", "--pre_compute_text_embeddings", "--text_encoder_use_attention_mask",
-                       "--skip_save_text_encoder", "--language_enhance", "-le"]
+                       "--skip_save_text_encoder"]
 
 
 def parse_args(argv=None):
@@ -74,6 +81,7 @@ def parse_args(argv=None):
     p.add_argument("--guidance_scale", type=float, default=7.5)
     p.add_argument("--do_classifier_free_guidance", type=bool, default=True)   # type=bool: any string -> True, as in the reference
     p.add_argument("--offset_noise", action="store_true", default=False)
+    p.add_argument("--language_enhance", "-le", action="store_true", default=False)
     for f in _IGNORED_VALUE_FLAGS:
         p.add_argument(f, default=None, help=argparse.SUPPRESS)
     for f in _IGNORED_BOOL_FLAGS:
@@ -86,6 +94,8 @@ def parse_args(argv=None):
     p.add_argument("--tiny", action="store_true", help="use the tiny test architecture (with --synthetic)")
     p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = max(train_batch_size, 8)); units (image, expand index) are independent")
     p.add_argument("--data_root", type=str, default="data")
+    p.add_argument("--gpus", type=int, default=1, help="spawn this many ranks (one per GPU) that shard the images like --total_split; "
+                   "weights are loaded once on rank 0 and broadcast over RCCL")
     p.add_argument("--device", type=str, default=None)
     args = p.parse_args(argv)
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
@@ -126,26 +136,20 @@ class ExpansionDataset:
 
     @staticmethod
     def from_dataset(args, cfg, eng):
-        """Caltech-101 listing as dataloader.py:272-315; latents and prompt embeddings as SDDataset.__init__ (dataloader.py:750-796)."""
-        root = os.path.join(args.data_root, "caltech-101", "101_ObjectCategories") if args.dataset == "caltech-101" else \
-            os.path.join(args.data_root, args.dataset)
-        if not os.path.isdir(root):
-            raise SystemExit("dataset directory %s not found (supported listings: caltech-101; or use --synthetic N)" % root)
-        classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)) and d not in ("BACKGROUND_Google", "Faces_easy"))
-        paths, targets = [], []
-        for ci, c in enumerate(classes):
-            for f in sorted(os.listdir(os.path.join(root, c))):
-                paths.append(os.path.join(root, c, f))
-                targets.append(ci)
-        names = [c.replace("_", " ") for c in classes]                     # dataloader.py:129
+        """Train listing as StandardDataLoader.load_dataset (dataloader.py:95-130; caltech-101 :272-315, stanford_cars :167-228);
+        latents and prompt embeddings as SDDataset.__init__ (dataloader.py:750-796)."""
+        from .datasets import load_train_listing
         from .preprocess import class_prompt_embeddings, load_or_encode_latents, load_tokenizer
-        # image latents: the reference's cache file if present, else the HIP VAE encoder fills it (dataloader.py:788-796)
+        paths, targets, names = load_train_listing(args.dataset, args.data_root)
+        # image latents: the reference's cache file if present (validated against this listing), else the HIP VAE encoder fills it
+        # (dataloader.py:788-796).  center_crop=False: the reference hard-codes it for SDDataset (generate_data.py:1001).
         lat = load_or_encode_latents(eng, args.dataset, args.pretrained_model_name_or_path, paths, args.resolution,
-                                     center_crop=args.center_crop, seed=args.seed or 0)
+                                     center_crop=False, seed=args.seed or 0)
         lat = torch.cat([x.float().cpu() for x in lat], dim=0)
-        # class prompts + the empty prompt through the HIP CLIP text encoder (dataloader.py:780-786)
+        # class prompts + the empty prompt through the HIP CLIP text encoder (dataloader.py:766-786)
         tokenizer = load_tokenizer(args.pretrained_model_name_or_path, args.revision)
-        class_embeds, uncond = class_prompt_embeddings(eng, tokenizer, args.dataset, names)
+        class_embeds, uncond = class_prompt_embeddings(eng, tokenizer, args.dataset, names, language_enhance=args.language_enhance,
+                                                       data_root=args.data_root)
         return ExpansionDataset(lat, class_embeds, uncond, torch.tensor(targets), names, paths)
 
     @staticmethod
@@ -223,6 +227,16 @@ class AsyncPNGWriter:
         return self.written
 
 
+def class_embedding(ds, target):
+    """`example["instance_prompt_ids"]` of SDDataset.__getitem__ (dataloader.py:832-835): the class prompt embedding, or with
+    --language_enhance `random.choice` among the class's sentences (python `random`, seeded by --seed like accelerate.set_seed)."""
+    ce = ds.class_embeds[int(target)]
+    if ce.dim() == 3:                       # [n_sentences, T, D]
+        import random
+        return ce[random.randrange(ce.shape[0])]
+    return ce
+
+
 def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     """The reference main loop, generate_data.py:1001-1009 (shard) and :1130-1236 (batches x expand index)."""
     from .launcher import shard_range
@@ -239,36 +253,66 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     dev = engine.device if engine is not None else torch.device("cpu")
     async_writer = AsyncPNGWriter(engine, writer) if hasattr(engine, "image_to_u8") and dev.type == "cuda" else None
     # Units of work = (train image i, expand index j), enumerated in the reference's order and filtered by its resume rule
-    # (a (batch, image_i) group is skipped when all of its PNGs exist, :1132-1143). The units are independent, so they are
+    # (a (batch, image_i) group is skipped when all of its PNGs exist, :1132-1143).  The units are independent, so they are
     # re-packed into engine batches of EB = engine.B images (>= train_batch_size): --train_batch_size 1 of the script of record
-    # would leave an MI355X mostly idle.
+    # would leave an MI355X mostly idle.  What is NOT independent of the reference batch is the energy: it is a `.mean()` over the
+    # train_batch_size images of a group (:709-719, :750-760), so every unit carries w = 1/|its group| into the engine
+    # (dd_set_sample_weights) and the logged score is the mean over the group, not over the engine batch.
     B = args.train_batch_size
     EB = engine.B
-    units = []
+    transform = args.guidance_type == "transform_guidance"
+    noise_gen = torch.Generator(device=rng_device)
+    noise_gen.manual_seed(int(args.seed or 0))
+    Cl = ds.latents.shape[1]
+    units = []      # (dataset index, path, group id, group size, e[4], b[4], prompt embedding, noise offset[C] or None)
+    n_groups = 0
     for s0 in range(0, len(idx), B):
         bidx = idx[s0:s0 + B]
+        prompts = [class_embedding(ds, ds.targets[i]) for i in bidx]      # one __getitem__ per image per batch (:1130)
         for image_i in range(args.first_image_index, args.num_images_per_prompt):
             paths = [output_path(args.output_dir, ds.class_names[int(ds.targets[i])], ds.image_paths[i], image_i) for i in bidx]
             if all(os.path.exists(p) for p in paths):
                 for p in paths:
                     print("File %s exists, so skipped." % p)
                 continue
-            units += [(i, p) for i, p in zip(bidx, paths)]
+            nb = len(bidx)
+            # :1164-1168: noise += 0.1 * randn(b, c, 1, 1)
+            off = 0.1 * torch.randn(nb, Cl, 1, 1, generator=noise_gen, device=rng_device).cpu() if args.offset_noise else None
+            if transform:
+                e = torch.rand([nb, 4, 1, 1])                                 # :692 CPU global RNG, one draw per reference batch
+                b = torch.zeros([nb, 4, 1, 1]).normal_(0, 1)                  # :694
+            else:
+                e = b = torch.zeros([nb, 4, 1, 1])
+            for k, (i, p) in enumerate(zip(bidx, paths)):
+                units.append((i, p, n_groups, nb, e[k], b[k], prompts[k], off[k] if off is not None else None))
+            n_groups += 1
+    group_scores = {}
     for u0 in range(0, len(units), EB):
         chunk = units[u0:u0 + EB]
         nb = len(chunk)
-        pad = [i for i, _ in chunk] + [chunk[-1][0]] * (EB - nb)            # ragged last batch: pad to the static batch
-        paths = [p for _, p in chunk]
+        chunk_p = chunk + [chunk[-1]] * (EB - nb)                           # ragged last batch: pad to the static batch
+        pad = [u[0] for u in chunk_p]
+        paths = [u[1] for u in chunk]
         lat = ds.latents[pad]
         tg = ds.targets[pad]
-        noise = torch.randn(lat.shape, generator=None, device=rng_device).to(lat.dtype)      # :1170 (global RNG)
-        e = torch.rand([EB, 4, 1, 1])                                   # :692 CPU global RNG
-        b = torch.zeros([EB, 4, 1, 1]).normal_(0, 1)                    # :694
-        emb = torch.cat([ds.uncond.expand(EB, -1, -1), ds.class_embeds[tg]])   # cat[negative, prompt], :1184
+        noise = torch.randn(lat.shape, generator=noise_gen, device=rng_device).to(lat.dtype).cpu()      # :1170
+        if args.offset_noise:
+            noise = noise + torch.stack([u[7] for u in chunk_p])
+        e = torch.stack([u[4] for u in chunk_p])
+        b = torch.stack([u[5] for u in chunk_p])
+        emb = torch.cat([ds.uncond.expand(EB, -1, -1), torch.stack([u[6] for u in chunk_p])])   # cat[negative, prompt], :1184
         engine.set_prompt(emb.to(dev))
+        if args.guidance_type and hasattr(engine, "set_sample_weights"):
+            engine.set_sample_weights([1.0 / u[3] for u in chunk] + [0.0] * (EB - nb))
         z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
         if args.guidance_type:
-            log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, float(score))
+            per_image = engine.image_scores().cpu().tolist() if hasattr(engine, "image_scores") else [float(score)] * EB
+            for u, sc in zip(chunk, per_image):
+                acc = group_scores.setdefault(u[2], [])
+                acc.append(sc)
+                if len(acc) == u[3]:                                          # the reference's log line (:1208-1216), one per batch
+                    log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, sum(acc) / len(acc))
+                    del group_scores[u[2]]
         if async_writer is not None:
             async_writer.submit(img[:nb], paths)
         else:

@@ -50,6 +50,56 @@ class PackedConv:
             self.bias = b.to(device)
 
 
+class PackedConvF32:
+    """fp32 packing of one guide conv (forward or dgrad form) for dd_op_conv_f32; w is [Cout][Cin/groups][KH][KW]."""
+
+    def __init__(self, w, pad, mode=0, groups=1, bias=None, device="cuda"):
+        w = w.detach().float().contiguous().cpu()
+        Cout, Cg, KH, KW = w.shape
+        Cin = Cg * groups
+        out4 = (C.c_int * 4)()
+        L = _lib.lib()
+        L.dd_pack_conv_weight_f32(C.c_void_p(w.data_ptr()), Cout, Cin, KH, KW, pad, mode, groups, None, None, out4)
+        self.N, self.K, self.cin, self.ntaps = out4[0], out4[1], out4[2], out4[3]
+        wp = np.zeros((self.N, self.K), dtype=np.float32)
+        tt = np.zeros((self.ntaps,), dtype=np.int32)
+        L.dd_pack_conv_weight_f32(C.c_void_p(w.data_ptr()), Cout, Cin, KH, KW, pad, mode, groups,
+                                  wp.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), out4)
+        self.w = torch.from_numpy(wp).to(device)
+        self.taptab = torch.from_numpy(tt).to(device)
+        self.groups = groups
+        gi, go = Cin // groups, Cout // groups
+        self.cpg_in, self.cpg_out = (go, gi) if mode else (gi, go)
+        self.bias = bias.detach().float().to(device) if bias is not None else None
+
+
+def conv_f32(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False):
+    """x: fp32 [B*H*W, ld] (ld % 4 == 0); returns fp32 y [B*Ho*Wo, roundup(N, 4)]."""
+    from ._lib import ConvF32Params
+    p = ConvF32Params()
+    M = B * Ho * Wo
+    y = torch.zeros((M, (pk.N + 3) // 4 * 4), device=x.device, dtype=torch.float32)
+    p.x, p.w, p.taptab, p.y = _ptr(x), _ptr(pk.w), _ptr(pk.taptab), _ptr(y)
+    p.x_ld, p.y_ld = x.stride(0), y.stride(0)
+    flags = 0
+    if pk.bias is not None:
+        flags |= CF_BIAS
+        p.bias = _ptr(pk.bias)
+    if res is not None:
+        flags |= CF_RES
+        p.res, p.res_ld = _ptr(res), res.stride(0)
+    if mask is not None:
+        flags |= CF_MASK
+        p.mask, p.mask_ld = _ptr(mask), mask.stride(0)
+    if relu:
+        flags |= CF_RELU
+    p.B, p.H, p.W, p.Ho, p.Wo, p.stride, p.shift, p.parity = B, H, W, Ho, Wo, stride, shift, parity
+    p.cin, p.ntaps, p.M, p.N, p.K = pk.cin, pk.ntaps, M, pk.N, pk.K
+    p.groups, p.cpg_in, p.cpg_out, p.flags = pk.groups, pk.cpg_in, pk.cpg_out, flags
+    check(_lib.lib().dd_op_conv_f32(C.byref(p), _stream()), "conv_f32")
+    return y[:, :pk.N]
+
+
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
               ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False):
     """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)]."""

@@ -75,14 +75,28 @@ def encode_image_latents(engine, image_paths, size, center_crop=False, seed=0, p
 
 
 def load_or_encode_latents(engine, dataset, model_name, image_paths, size, center_crop=False, seed=0, root="save/vae_embedding"):
-    """The cache logic of dataloader.py:788-796 (same path, same file format)."""
+    """The cache logic of dataloader.py:788-796 (same path, same file format: a positional list of [1,4,L,L] tensors).  The cache
+    pairs latents with images by POSITION only, so a listing that differs from the one that wrote it would silently pair latents
+    with the wrong paths / labels / prompts: a cache written here stores its path list next to it (`image_latents.paths.json`) and
+    is refused when the current listing differs; a cache written by the reference (no side file) must at least have its length."""
+    import json
     embed_dir = os.path.join(root, dataset, model_name.replace("/", "--"))
     embed_path = os.path.join(embed_dir, "image_latents.pt")
+    side = os.path.join(embed_dir, "image_latents.paths.json")
+    rel = [os.path.join(os.path.basename(os.path.dirname(p)), os.path.basename(p)) for p in image_paths]
     if os.path.exists(embed_path):
-        return torch.load(embed_path, map_location="cpu")
+        latents = torch.load(embed_path, map_location="cpu")
+        if len(latents) != len(image_paths):
+            raise SystemExit("latent cache %s holds %d latents but the %s train listing has %d images: it was written for a different "
+                             "listing; delete it to re-encode" % (embed_path, len(latents), dataset, len(image_paths)))
+        if os.path.exists(side) and json.load(open(side)) != rel:
+            raise SystemExit("latent cache %s was written for a different image order than the current %s listing (see %s); delete "
+                             "both files to re-encode" % (embed_path, dataset, side))
+        return latents
     os.makedirs(embed_dir, exist_ok=True)
     latents = encode_image_latents(engine, image_paths, size, center_crop, seed)
     torch.save(latents, embed_path)
+    json.dump(rel, open(side, "w"))
     return latents
 
 
@@ -110,8 +124,21 @@ def encode_token_ids(engine, ids):
     return torch.cat([engine.text_encode(ids[i:i + step]).cpu() for i in range(0, ids.shape[0], step)])
 
 
-def class_prompt_embeddings(engine, tokenizer, dataset, class_names):
-    """classes_prompts / uncond_input of SDDataset.__init__ (dataloader.py:780-786, language_enhance off)."""
-    template = CUSTOM_TEMPLATES[dataset]
+def class_prompt_embeddings(engine, tokenizer, dataset, class_names, language_enhance=False, data_root="data"):
+    """classes_prompts / uncond_input of SDDataset.__init__ (dataloader.py:766-786).  Returns (per-class embeddings, uncond):
+    a tensor [C, T, D], or with --language_enhance a list of [n_sentences_c, T, D] tensors from `data/<dataset>_le.pkl`
+    (dict class name -> sentences, `_` -> ' ' in the keys, :769-778)."""
+    if language_enhance:
+        template = np.load(os.path.join(data_root, "%s_le.pkl" % dataset), allow_pickle=True)
+        template = {k.replace("_", " "): v for k, v in template.items()}
+        sentences = [list(template[x]) for x in class_names]
+        flat = [p for ss in sentences for p in ss] + [""]
+        emb = compute_text_embeddings(engine, tokenizer, flat)
+        out, o = [], 0
+        for ss in sentences:
+            out.append(emb[o:o + len(ss)])
+            o += len(ss)
+        return out, emb[-1:]
+    template = CUSTOM_TEMPLATES.get(dataset, "a photo of a {}.")
     emb = compute_text_embeddings(engine, tokenizer, [template.format(x) for x in class_names] + [""])
     return emb[:-1], emb[-1:]

@@ -121,6 +121,14 @@ int dd_direct_guidance(dd_engine* e, const float* z, const int* targets, int ste
                        float* score_out, float* grad_z_out, int B, void* stream);
 int dd_decode(dd_engine* e, const float* z, float* image_out, int denormalize, int B, void* stream);
 int dd_expand(dd_engine* e, const dd_expand_args* a, void* stream);
+/* The reference's energy is a `.mean()` over ITS batch (train_batch_size images: generate_data.py:709, :716, :751, :758), so each
+ * image's gradient carries 1/train_batch_size.  A caller that packs several reference batches into one engine batch passes
+ * w[i] = 1 / |reference batch of image i| (0 for padding rows): HOST float[B], or NULL to return to the default 1/B.  Applies to
+ * every later guidance call; score_out then holds sum_i w[i] E_i. */
+int dd_set_sample_weights(dd_engine* e, const float* w_host, int B);
+/* per-image energies E_i of the most recent guidance call (for transform guidance already divided by guidance_period, :719):
+ * DEVICE float[B]; the caller averages them over its reference batches for the score log line (:1208-1216) */
+int dd_get_image_scores(dd_engine* e, float* scores_out, int B, void* stream);
 /* output stage: image DEVICE fp32 [B,3,8L,8L] in [0,1] -> DEVICE uint8 [B,8L,8L,3] (mul 255, add 0.5, clamp, truncate: save_image, :1227-1234) */
 int dd_image_to_u8(dd_engine* e, const float* image, uint8_t* out_hwc, int B, void* stream);
 /* images: DEVICE fp32 [B,3,S,S] (S = guide_input_size) -> feats DEVICE fp32 [B, D] */

@@ -13,6 +13,8 @@
  *   dd_op_attention_*    scaled-dot-product attention (self, cross, VAE mid block) (:112, :701)
  *   dd_op_cfg_ddim*      classifier-free guidance + DDIMScheduler.step (:116-119)
  *   dd_op_bicubic*       F.interpolate(..., (224,224), 'bicubic') (:704, :745)
+ *   dd_op_conv_f32       timm conv+BN(+ReLU) of image_encoder.encode_image and its input-gradient in exact fp32
+ *                        (model_utils.py:29-41; generate_data.py:705, :721, :746, :761): v_mfma_f32_32x32x2_f32
  *   dd_op_energy         prototype energy terms (:707-717, :747-759)
  *   dd_op_transform_update  SGD step on (e, b), re-affine, linfball_proj (:721-728, :124-137)
  */
@@ -29,6 +31,7 @@ struct ConvGemmParams;
 struct GroupNormParams;
 struct LayerNormParams;
 struct AttnParams;
+struct ConvF32Params;
 
 int dd_op_conv_gemm(const struct ConvGemmParams* p, size_t partial_cap_bytes, void* stream);
 int dd_op_groupnorm_fwd(const struct GroupNormParams* p, void* stream);
@@ -44,6 +47,12 @@ int dd_op_attention_bwd(const struct AttnParams* p, void* stream);
 size_t dd_op_attention_gemm_workspace(int Nq, int Nk, int D, int bwd);
 int dd_op_attention_gemm_fwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
 int dd_op_attention_gemm_bwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
+
+/* fp32 implicit-GEMM convolution / dgrad of the guide network (guide_f32.hip) and its weight packing: w is
+ * [Cout][Cin/groups][KH][KW] fp32 (torch grouped layout); out4 = {N, K, cin, ntaps}; wp may be NULL to query sizes */
+int dd_op_conv_f32(const struct ConvF32Params* p, void* stream);
+int dd_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW, int pad, int mode, int groups, float* wp, int* taptab,
+                            int* out4);
 
 /* host-side weight packing: returns N, K, cin, ntaps through out[4]; wp may be NULL to query sizes */
 int dd_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int pad, int mode, int geglu,

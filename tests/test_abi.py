@@ -39,8 +39,9 @@ def test_struct_mirrors_match_c_layout():
     #include <stdio.h>
     #include "distdiff_amd/csrc/kernels.h"
     #include "include/distdiff_hip.h"
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ConvGemmParams), sizeof(GroupNormParams), sizeof(LayerNormParams),
-                       sizeof(AttnParams), sizeof(dd_config), sizeof(dd_sampler_params), sizeof(dd_expand_args)); return 0; }
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ConvGemmParams), sizeof(GroupNormParams), sizeof(LayerNormParams),
+                       sizeof(AttnParams), sizeof(dd_config), sizeof(dd_sampler_params), sizeof(dd_expand_args), sizeof(ConvF32Params));
+                return 0; }
     '''
     exe = "/tmp/dd_sizes"
     cpp = "/tmp/dd_sizes.cpp"
@@ -51,7 +52,7 @@ def test_struct_mirrors_match_c_layout():
     sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
     from distdiff_amd import _lib, engine
     got = [ctypes.sizeof(x) for x in (_lib.ConvGemmParams, _lib.GroupNormParams, _lib.LayerNormParams, _lib.AttnParams,
-                                      engine.DDConfig, engine.DDSamplerParams, engine.DDExpandArgs)]
+                                      engine.DDConfig, engine.DDSamplerParams, engine.DDExpandArgs, _lib.ConvF32Params)]
     assert got == sizes, (got, sizes)
 
 
