@@ -222,6 +222,7 @@ struct dd_engine {
   float* score_tmp = nullptr;
   float* sample_w = nullptr; bool sample_w_set = false;   // per-image energy weights (dd_set_sample_weights); default 1/B
   float* image_scores = nullptr;                         // per-image energies of the last guidance call
+  const float* image_override = nullptr;                 // dd_debug_set_image: parity tests evaluate the guide at a given image
   size_t total_bytes = 0;
   double flops = 0;
   Profiler prof;
@@ -1079,6 +1080,8 @@ void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
   const Tn& img = E->vae.t[E->vae_out];
   const Tn& gin = E->guide.t[E->guide_in];
   // the decoder's conv_out stores the image in fp32: image, bicubic resize and the whole guide stay fp32
+  if (E->image_override)   // parity tests: the guide (its ReLU / max-pool masks) is evaluated AT the given image, gradients flow as usual
+    HIPCHK(launch_nchw_to_nhwc_f32(E->image_override, act_f32(vc, img), c.max_batch, c.vae_out_channels, img.H, img.W, img.ld, img.ld, s));
   HIPCHK(launch_bicubic_f32(act_f32(vc, img), img.ld, act_f32(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
   run_fwd(E->guide, gc);
   const Tn& f = E->guide.t[E->guide_feat];
@@ -1657,28 +1660,38 @@ int dd_profile_read(dd_engine* E, double* out12) {
   });
 }
 
-// ---- debug introspection: copy activation / gradient of tensor `idx` of program `prog` (0 unet, 1 vae, 2 guide), instance 0,
+// ---- debug introspection: copy activation / gradient of tensor `idx` of program `prog` (0 unet, 1 vae, 2 guide; + 16 * instance)
 // to a HOST fp32 buffer [rows*ld]; info4 = {rows, C, ld, is_f32}. Synchronises.
-int dd_debug_tensor(dd_engine* E, int prog, int idx, int want_grad, float* host_out, int* info4) {
-  if (!E || prog < 0 || prog > 2) return DD_ERR_ARG;
+int dd_debug_tensor(dd_engine* E, int prog_inst, int idx, int want_grad, float* host_out, int* info4) {
+  const int prog = prog_inst & 15, k = prog_inst >> 4;   // bits 4.. select the instance (chained guided step) of an activation
+  if (!E || prog < 0 || prog > 2 || k < 0 || k >= (int)E->inst.size()) return DD_ERR_ARG;
   DD_TRY(E, {
     Program& P = prog == 0 ? E->unet : prog == 1 ? E->vae : E->guide;
+    if (idx < 0) idx += (int)P.t.size();   // negative: from the end (-1 = the program's output tensor)
     if (idx < 0 || idx >= (int)P.t.size()) throw std::runtime_error("tensor index out of range");
     const Tn& t = P.t[idx];
     if (info4) { info4[0] = t.rows; info4[1] = t.C; info4[2] = t.ld; info4[3] = t.f32 ? 1 : 0; }
     if (!host_out) return DD_OK;
     HIPCHK(hipDeviceSynchronize());
-    char* base = want_grad ? E->grad_slab + t.goff : (prog == 0 ? E->inst[0].unet : prog == 1 ? E->inst[0].vae : E->inst[0].guide) + t.off;
+    const dd_engine::Inst& I = E->inst[k];
+    char* slab = prog == 0 ? I.unet : prog == 1 ? I.vae : I.guide;
+    if (!want_grad && !slab) throw std::runtime_error("this instance has no slab for that program");
+    char* base = want_grad ? E->grad_slab + t.goff : slab + t.off;
     const size_t n = (size_t)t.rows * t.ld;
     if ((t.f32 && !want_grad) || (want_grad && P.f32)) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
     else {
       std::vector<bf16_t> tmp(n);
-      // views share rows with their parent: copy row by row
-      HIPCHK(hipMemcpy2D(tmp.data(), (size_t)t.ld * 2, base, (size_t)t.ld * 2, (size_t)t.ld * 2, 1, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(tmp.data(), base, n * 2, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < n; ++i) host_out[i] = host_bf2f(tmp[i]);
     }
   });
+}
+// parity-test hook: image DEVICE fp32 [B,3,8L,8L] (not denormalised) replaces the decoder's output in front of the bicubic resize of
+// every later guided forward (the gradient still flows through the decoder); NULL switches it off.  The caller keeps the buffer alive.
+int dd_debug_set_image(dd_engine* E, const float* image) {
+  if (!E) return DD_ERR_ARG;
+  E->image_override = image;
+  return DD_OK;
 }
 int dd_debug_num_tensors(dd_engine* E, int prog) {
   if (!E || prog < 0 || prog > 2) return DD_ERR_ARG;

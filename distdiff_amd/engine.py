@@ -77,6 +77,7 @@ def _declare(l):
     l.dd_profile_read.argtypes = [vp, vp]
     l.dd_debug_tensor.argtypes = [vp, i, i, i, vp, vp]
     l.dd_debug_num_tensors.argtypes = [vp, i]
+    l.dd_debug_set_image.argtypes = [vp, vp]
     l.dd_workspace_bytes.argtypes = [vp]
     l.dd_workspace_bytes.restype = C.c_size_t
     l.dd_flops_last.argtypes = [vp]
@@ -333,13 +334,25 @@ class Engine:
         names = ["conv_gemm", "attention", "norm", "other"]
         return {n: {"ms": out[3 * k], "flops": out[3 * k + 1], "ops": int(out[3 * k + 2])} for k, n in enumerate(names)}
 
-    def debug_tensor(self, prog, idx, grad=False):
+    def debug_tensor(self, prog, idx, grad=False, instance=0):
+        prog = prog | (instance << 4)
         info = (C.c_int * 4)()
         self._chk(self.L.dd_debug_tensor(self._h, prog, idx, int(grad), None, info), "dd_debug_tensor")
         rows, Cc, ld, f32 = list(info)
         out = torch.empty(rows * ld, dtype=torch.float32)
         self._chk(self.L.dd_debug_tensor(self._h, prog, idx, int(grad), vp(out.data_ptr()), info), "dd_debug_tensor")
         return out.reshape(rows, ld)[:, :Cc]
+
+    def guided_image(self, instance=0):
+        """The fp32 image [B,3,8L,8L] (not denormalised) the decoder produced in chained guided step `instance` of the most recent
+        guidance call: the exact input of the bicubic resize + guide network (used by the parity tests)."""
+        L8 = 8 * self.cfg.latent_size
+        return self.debug_tensor(1, -1, instance=instance).reshape(self.B, L8, L8, 3).permute(0, 3, 1, 2).contiguous()
+
+    def set_guide_image(self, image):
+        """Parity-test hook (dd_debug_set_image): evaluate the guide of later guided forwards at `image` [B,3,8L,8L]; None = off."""
+        self._override = self._f(image) if image is not None else None
+        self._chk(self.L.dd_debug_set_image(self._h, _p(self._override)), "dd_debug_set_image")
 
     def debug_num_tensors(self, prog):
         return int(self.L.dd_debug_num_tensors(self._h, prog))

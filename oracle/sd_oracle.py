@@ -377,22 +377,27 @@ def energy(args, feats, targets, global_proto, local_proto):
     return score
 
 
-def _guide_features(vae, guide, x0, size):
+def _guide_features(vae, guide, x0, size, image_at=None):
     img = vae.decode(x0 / vae.config.scaling_factor)[0]          # postprocess(do_denormalize=False) is the identity
+    if image_at is not None:
+        # test hook (not in the reference): evaluate the guide -- i.e. its ReLU / max-pool masks -- AT a given image while the
+        # gradient still flows through this decoder (straight-through).  The guide's input-gradient is piecewise constant in the
+        # image, so a comparison of two implementations of the energy gradient is only meaningful at the same image.
+        img = img + (image_at - img).detach()
     img = F.interpolate(img, size=(size, size), mode="bicubic")
     return guide.encode_image(img).float()
 
 
 def transform_guidance(args, latents, targets, sub_timesteps, scheduler, unet, prompt_embeds, vae, guide, e, b,
-                       global_proto, local_proto, guide_size=224):
+                       global_proto, local_proto, guide_size=224, images_at=None):
     """generate_data.py:687-732 with the random draws (e ~ U[0,1), b ~ N(0,1), :692-695) passed in explicitly."""
     e = e.clone().requires_grad_(True)
     b = b.clone().requires_grad_(True)
     x = latents * (1 + e) + b
     score = 0.0
-    for t in sub_timesteps:
+    for k, t in enumerate(sub_timesteps):
         x, x0 = denoise_one_step(args, x, scheduler, t, unet, prompt_embeds)
-        feats = _guide_features(vae, guide, x0, guide_size)
+        feats = _guide_features(vae, guide, x0, guide_size, images_at[k] if images_at is not None else None)
         score = score + energy(args, feats, targets, global_proto, local_proto)
     score = score / args.guidance_period
     ge, gb = torch.autograd.grad(score, [e, b])
@@ -406,11 +411,11 @@ def transform_guidance(args, latents, targets, sub_timesteps, scheduler, unet, p
 
 
 def direct_guidance(args, latents, targets, t, scheduler, unet, prompt_embeds, vae, guide, global_proto, local_proto,
-                    guide_size=224):
+                    guide_size=224, image_at=None):
     """generate_data.py:735-767."""
     z = latents.clone().requires_grad_(True)
     z_next, x0 = denoise_one_step(args, z, scheduler, t, unet, prompt_embeds)
-    feats = _guide_features(vae, guide, x0, guide_size)
+    feats = _guide_features(vae, guide, x0, guide_size, image_at)
     feats = feats / feats.norm(dim=-1, keepdim=True)
     score = energy(args, feats, targets, global_proto, local_proto)
     (g,) = torch.autograd.grad(score, z)

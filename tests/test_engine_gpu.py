@@ -1,16 +1,21 @@
 """Parity of the HIP engine (through the production C ABI, include/distdiff_hip.h) against the CPU oracle and the
 committed golden fixtures (produced by the reference's own sampler functions, tests/golden/make_fixtures.py).
 
-Tolerance statement (bf16 storage + bf16 MFMA inputs, fp32 accumulation, vs the fp32 oracle), relative L2 error:
-  forward tensors (eps, z_prev, x0, decoded image, guide features)  <= 3 %
-  VJP of UNet / VAE decoder with random cotangents                  <= 5 %
-  VJP of the ReLU/max-pool guide network                            <= 30 %: ReLU masks of activations within bf16 rounding of 0
-      flip, torch's own bf16 autograd differs from fp32 by ~20 % on this network (tools/engine_check.py)
-  (e, b) gradients of transform guidance (chained through the guide)   <= 40 % (same mask-flip noise)
-  guidance scores                                                   <= 1 %
-  latents after transform guidance                                  <= 8 % vs the reference (gradient-noise dominated: 3.8-5.8 % measured
-      across arithmetically equivalent builds), and == the update rule applied to the engine's own gradient to 2e-4
-  latents after direct guidance / after the whole loop              <= 5 %, decoded image max abs error <= 0.15 (of [0,1])
+Tolerance statement (UNet / VAE: bf16 storage + bf16 MFMA inputs, fp32 accumulation; guide network, bicubic resize, energy: exact
+fp32; all vs the fp32 oracle), relative L2 error:
+  forward tensors (eps, z_prev, x0, decoded image)                  <= 3 %   (measured 1.3-2.3 %)
+  guide features / guide VJP (fp32 v_mfma_f32_32x32x2_f32)          <= 1e-4 / 2e-3   (measured 2e-7 / 4e-7)
+  VJP of UNet / VAE decoder with random cotangents                  <= 5 % / 3 %   (measured 2.1 % / 0.9 %)
+  guidance scores                                                   <= 0.5 %
+  energy gradient, masks at the SAME image (test_energy_gradient_at_the_same_image): g_z of direct guidance, (e, b) gradients of
+      transform guidance                                            <= 5 %
+  energy gradient against the oracle's own forward point: NOT a parity statement at the 5 % level for any bf16 UNet -- the guide's
+      input-gradient is piecewise constant in the image (ReLU / max-pool masks), and in the fp32 oracle itself a 1 % perturbation
+      of the image moves it by 14-20 % (tests/test_oracle.py::test_guide_gradient_conditioning).  With the engine's x0 within
+      2.3 % of the oracle's: (e, b) gradients <= 12 % (measured 5-9 %), per-pixel g_z of direct guidance <= 45 % (measured 36 %)
+  latents after transform guidance                                  <= 5 % vs the reference (measured 3.7 %), and == the update rule
+      applied to the engine's own gradient to 2e-4
+  latents after direct guidance / after the whole loop              <= 3 %, decoded image max abs error <= 0.08 (of [0,1])
 """
 import os
 
@@ -79,7 +84,7 @@ def test_unet_decode_guide_forward(setup, fx):
     d = eng.decode(fx["ref_denoise_x0"], denormalize=True)
     assert float(d.min()) >= 0.0 and float(d.max()) <= 1.0
     assert (d.cpu() - (img / 2 + 0.5).clamp(0, 1)).abs().max() < 0.06
-    assert rel(eng.guide_encode(gi), f) < 0.02
+    assert rel(eng.guide_encode(gi), f) < 1e-4
 
 
 def test_module_vjps_vs_autograd(setup, fx):
@@ -101,7 +106,7 @@ def test_module_vjps_vs_autograd(setup, fx):
     gf = torch.randn(B, cfg.guide.feature_dim, generator=g)
     gir = gi.clone().requires_grad_(True)
     (gr,) = torch.autograd.grad(guide.encode_image(gir), gir, gf)
-    assert rel(eng.guide_vjp(gi, gf), gr) < 0.30
+    assert rel(eng.guide_vjp(gi, gf), gr) < 2e-3       # exact fp32 guide (guide_f32.hip): summation order only
     # linearity of the hand-derived VJP in the cotangent (size-independent property)
     a = eng.unet_vjp(z, 5, gg)
     b = eng.unet_vjp(z, 5, 2.0 * gg)
@@ -112,7 +117,7 @@ def test_transform_guidance_vs_reference_fixture(setup, fx):
     cfg, eng, models, O = setup
     first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
     z, score, gz0 = eng.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
-    assert abs(score.item() - float(fx["ref_transform_score"])) < 0.01 * abs(float(fx["ref_transform_score"]))
+    assert abs(score.item() - float(fx["ref_transform_score"])) < 0.005 * abs(float(fx["ref_transform_score"]))
     assert float((z.cpu() - fx["z"]).abs().max()) <= fx["args"]["constraint_value"] + 1e-5   # L-inf ball (generate_data.py:124-137)
     # the update rule itself (:696, :721-728), exactly: e -= rho*ge, b -= rho*gb, re-affine, clamp (lower bound first) -- evaluated
     # with the engine's own gradient, so this part is free of the gradient noise discussed below
@@ -124,10 +129,8 @@ def test_transform_guidance_vs_reference_fixture(setup, fx):
     new = torch.where(new < lo, lo, new)
     new = torch.where(new > hi, hi, new)
     assert (z.cpu() - new).abs().max().item() < 2e-4
-    # against the reference's own output the latents inherit the noise of the chained VJP (ReLU masks of activations within bf16
-    # rounding of zero flip, module docstring): 0.038 - 0.058 was measured across arithmetically equivalent builds (a 1-ulp change
-    # anywhere re-draws the flips), so the bound carries that spread
-    assert rel(z, fx["ref_transform_z"]) < 0.08
+    # against the reference's own output (measured 0.037; the forward x0 error of the bf16 UNet re-draws some of the guide's masks)
+    assert rel(z, fx["ref_transform_z"]) < 0.05
     # gradient wrt (e, b) against the oracle's autograd
     args = O.SamplerArgs(**fx["args"])
     unet, vae, guide, sched = models
@@ -136,8 +139,78 @@ def test_transform_guidance_vs_reference_fixture(setup, fx):
                                           fx["Pc"], fx["Pg"], cfg.guide.input_size)
     ge_h = (gz0.cpu() * fx["z"]).sum((2, 3), keepdim=True)
     gb_h = gz0.cpu().sum((2, 3), keepdim=True)
-    # chained VJP through the ReLU guide: dominated by the bf16 mask-flip noise described in the module docstring
-    assert rel(ge_h, ge) < 0.40 and rel(gb_h, gb) < 0.40
+    # against the oracle's OWN forward point (its masks, not the engine's): bounded by the conditioning of the guide's gradient, see
+    # the module docstring; measured 0.085 / 0.053.  The parity statement proper is test_energy_gradient_at_the_same_image.
+    assert rel(ge_h, ge) < 0.12 and rel(gb_h, gb) < 0.12
+
+
+def test_energy_gradient_at_the_same_image(setup, fx):
+    """The hand-derived energy gradient (A9: replaces torch.autograd.grad at generate_data.py:721 / :761) against the oracle's autograd
+    with the guide evaluated AT the engine's decoded image (straight-through hook of the oracle: same ReLU / max-pool masks on both
+    sides, gradient through the oracle's own decoder, DDIM/CFG algebra and UNet)."""
+    cfg, eng, models, O = setup
+    unet, vae, guide, sched = models
+    args = O.SamplerArgs(**fx["args"])
+    emb = torch.cat([fx["negative_embeds"], fx["prompt_embeds"]])
+    first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
+    # direct guidance: per-pixel g_z
+    zn, x0, score, gz = eng.direct_guidance(fx["z"], fx["targets"], first)
+    img = eng.guided_image(0)
+    _, _, sc_ref, g_ref = O.direct_guidance(args, fx["z"], fx["targets"], fx["guide_timesteps"][0], sched, unet, emb, vae, guide, fx["Pc"],
+                                            fx["Pg"], cfg.guide.input_size, image_at=img)
+    assert abs(score.item() - float(sc_ref)) < 1e-4 * abs(float(sc_ref))       # same image, fp32 guide: the energies agree to fp32
+    assert rel(gz, g_ref) < 0.05, rel(gz, g_ref)
+    # transform guidance: two chained steps, (e, b) gradients
+    z, score, gz0 = eng.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
+    imgs = [eng.guided_image(0), eng.guided_image(1)]
+    _, s_ref, (ge, gb) = O.transform_guidance(args, fx["z"], fx["targets"], fx["guide_timesteps"], sched, unet, emb, vae, guide, fx["e"],
+                                              fx["b"], fx["Pc"], fx["Pg"], cfg.guide.input_size, images_at=imgs)
+    assert abs(score.item() - float(s_ref)) < 1e-4 * abs(float(s_ref))
+    ge_h = (gz0.cpu() * fx["z"]).sum((2, 3), keepdim=True)
+    gb_h = gz0.cpu().sum((2, 3), keepdim=True)
+    assert rel(ge_h, ge) < 0.05 and rel(gb_h, gb) < 0.05, (rel(ge_h, ge), rel(gb_h, gb))
+
+
+def test_energy_mean_runs_over_the_reference_batch(hip_lib, fx):
+    """The reference's energy is a `.mean()` over ITS batch (train_batch_size images, generate_data.py:709-719, 750-760).  When the CLI
+    packs 2 reference batches of 1 image into one engine batch of 2 (dd_set_sample_weights w = [1, 1]) each image must get the
+    gradient a B = 1 engine gives it -- not half of it."""
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    a = fx["args"]
+    first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
+    emb_n, emb_p = fx["negative_embeds"], fx["prompt_embeds"]
+
+    def make(B):
+        cfg = tiny_config(max_batch=B)
+        eng = Engine(cfg, synthetic_weights(cfg, seed=0, num_classes=5), enable_grad=True, max_guidance_period=2)
+        sched = DDIMSchedule(cfg.scheduler)
+        eng.set_schedule(sched.set_timesteps(fx["n_steps"]), sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=a["guidance_scale"],
+                         gs=a["gs"], ls=a["ls"], rho=a["rho"], constraint_value=a["constraint_value"], guidance_period=a["guidance_period"])
+        eng.set_prototypes(fx["Pc"], fx["Pg"])
+        return eng
+
+    e2 = make(2)
+    e2.set_prompt(torch.cat([emb_n, emb_p]).cuda())
+    _, s_mean, g_mean = e2.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)      # default: mean over the engine batch
+    e2.set_sample_weights([1.0, 1.0])
+    _, s_sum, g_w = e2.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
+    per_image = e2.image_scores().cpu()
+    assert torch.allclose(g_w, 2.0 * g_mean, rtol=1e-3, atol=1e-7)
+    assert abs(per_image.mean().item() - s_mean.item()) < 1e-4 * s_mean.item() and abs(per_image.sum().item() - s_sum.item()) < 1e-4 * s_sum.item()
+    e2.set_sample_weights([1.0, 0.0])                      # a padding row neither contributes to the score nor receives a gradient
+    _, s_pad, g_pad = e2.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
+    assert float(g_pad[1].abs().max()) == 0.0 and abs(s_pad.item() - per_image[0].item()) < 1e-4 * s_pad.item()
+    e2.close()
+    e1 = make(1)
+    for i in range(2):
+        e1.set_prompt(torch.cat([emb_n[i:i + 1], emb_p[i:i + 1]]).cuda())
+        _, s1, g1 = e1.transform_guidance(fx["z"][i:i + 1], fx["targets"][i:i + 1], fx["e"][i:i + 1], fx["b"][i:i + 1], first, 2)
+        assert abs(s1.item() - per_image[i].item()) < 2e-3 * s1.item()
+        assert rel(g_w[i:i + 1], g1) < 0.05, rel(g_w[i:i + 1], g1)       # different batch -> different tile paths / rounding patterns
+    e1.close()
 
 
 def test_direct_guidance_vs_reference_fixture(setup, fx):
@@ -147,6 +220,7 @@ def test_direct_guidance_vs_reference_fixture(setup, fx):
     assert abs(score.item() - float(fx["ref_direct_score"])) < 0.01 * abs(float(fx["ref_direct_score"]))
     assert rel(zn, fx["ref_direct_z_next"]) < 0.03
     assert rel(x0, fx["ref_direct_x0"]) < 0.04
+    assert abs(score.item() - float(fx["ref_direct_score"])) < 0.002 * abs(float(fx["ref_direct_score"]))
 
 
 @pytest.mark.parametrize("gt", ["transform_guidance", "direct_guidance", None])
@@ -155,16 +229,25 @@ def test_expand_loop_vs_golden(setup, fx, gt):
     first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
     key = gt or "none"
     z, img, score = eng.expand(fx["lat"], fx["noise"], fx["e"], fx["b"], fx["targets"], fx["start_index"], gt, first, 2)
-    assert rel(z, fx["expand_%s_z" % key]) < 0.05
+    assert rel(z, fx["expand_%s_z" % key]) < 0.03
     ref = fx["expand_%s_img_u8" % key].float() / 255.0
     err = (img.cpu() - ref).abs()
-    assert float(err.max()) < 0.15
+    assert float(err.max()) < 0.08
+    # output stage (f-3, generate_data.py:1227-1234): dd_image_to_u8 bytes == save_image's mul(255).add_(0.5).clamp_(0,255).to(uint8)
+    # of the engine's own fp32 image, exactly; and within the forward tolerance of the golden bytes
+    u8 = eng.image_to_u8(img).cpu()
+    mine = img.cpu().mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert torch.equal(u8, mine)
+    gold = fx["expand_%s_img_u8" % key]
+    gold = gold.permute(0, 2, 3, 1) if gold.shape[1] == 3 else gold
+    d = (u8.int() - gold.int()).abs()
+    assert int(d.max()) <= 21 and float((d <= 4).float().mean()) > 0.9, (int(d.max()), float((d <= 4).float().mean()))
     mse = float((err ** 2).mean())
     psnr = 10 * torch.log10(torch.tensor(1.0 / mse)).item()
     assert psnr > 30.0, psnr
     if gt:
         s_ref = float(fx["expand_%s_score" % key])
-        assert abs(score.item() - s_ref) < 0.01 * abs(s_ref)
+        assert abs(score.item() - s_ref) < 0.005 * abs(s_ref)
     # determinism: no float atomics on the data path -> bitwise identical on a second run
     z2, img2, _ = eng.expand(fx["lat"], fx["noise"], fx["e"], fx["b"], fx["targets"], fx["start_index"], gt, first, 2)
     assert torch.equal(z, z2) and torch.equal(img, img2)

@@ -198,3 +198,36 @@ def test_vae_encode_oracle_primitives():
     a = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
     b = F.conv2d(F.pad(x, (1, 1, 1, 1)), w, stride=2)
     assert a.shape[-1] == S // 2 and not torch.allclose(a, b[..., : S // 2, : S // 2])
+
+
+def test_guide_gradient_conditioning():
+    """Why the energy-gradient parity tests compare at the SAME image (tests/test_engine_gpu.py::test_energy_gradient_at_the_same_image):
+    the input-gradient of the ReLU / max-pool guide (encode_image, model_utils.py:29-41; differentiated by torch.autograd.grad at
+    generate_data.py:721 / :761) is piecewise constant in the image.  In the fp32 oracle itself a relative perturbation of the image of
+    1e-3 already moves it by several per cent and one bf16 rounding of the image by ~5 %, while the features move by < 0.1 %: a
+    tolerance on this gradient across two forward paths that differ by a bf16 UNet (x0 within ~2 %) says nothing about the VJP code."""
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.weights import synthetic_weights
+    cfg = tiny_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=5)
+    guide = O.GuideOracle(cfg, w["guide"])
+    S = cfg.guide.input_size
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, S, S, generator=g) * 0.5
+    gf = torch.randn(2, cfg.guide.feature_dim, generator=g)
+
+    def vjp(xx):
+        xr = xx.clone().requires_grad_(True)
+        f = guide.encode_image(xr)
+        (gr,) = torch.autograd.grad(f, xr, gf)
+        return f.detach(), gr
+
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    f0, g0 = vjp(x)
+    n = torch.randn(x.shape, generator=g)
+    f1, g1 = vjp(x + 1e-3 * n * x.norm() / n.norm())
+    assert rel(f1, f0) < 1e-3 and rel(g1, g0) > 0.02
+    f2, g2 = vjp(x + 1e-2 * n * x.norm() / n.norm())
+    assert rel(f2, f0) < 1e-2 and rel(g2, g0) > 0.08
+    f3, g3 = vjp(x.bfloat16().float())
+    assert rel(g3, g0) > 0.02
