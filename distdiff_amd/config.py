@@ -63,12 +63,32 @@ class GuideConfig:
     planes: Tuple[int, ...] = (64, 128, 256, 512)
     blocks: Tuple[int, ...] = (3, 4, 6, 3)
     expansion: int = 4
+    cardinality: int = 1               # timm Bottleneck: width = int(planes * base_width / 64) * cardinality; conv2 has `cardinality` groups
+    base_width: int = 64               # resnet50 (1, 64), resnext50_32x4d (32, 4), wide_resnet50_2 (1, 128)  (model_utils.py:47-79)
     bn_eps: float = 1e-5
     input_size: int = 224              # F.interpolate(..., (224,224), 'bicubic') generate_data.py:704
 
     @property
     def feature_dim(self):
         return self.planes[-1] * self.expansion
+
+    def width(self, planes):
+        return int(planes * self.base_width / 64) * self.cardinality
+
+
+# the reference's guide architectures that are ResNet Bottleneck networks (model_utils.py:47-79); mobilenetv2 and open_clip_vit_b32
+# (:64-70, :80-87) are other network families and are not built
+GUIDE_ARCHS = {
+    "resnet50": dict(cardinality=1, base_width=64),
+    "resnext50": dict(cardinality=32, base_width=4),          # timm resnext50_32x4d
+    "wideresnet50": dict(cardinality=1, base_width=128),      # timm wide_resnet50_2
+}
+
+
+def guide_config(arch="resnet50", **kw):
+    if arch not in GUIDE_ARCHS:
+        raise NotImplementedError("guide arch %r is not built (built: %s)" % (arch, ", ".join(sorted(GUIDE_ARCHS))))
+    return GuideConfig(arch=arch, **GUIDE_ARCHS[arch], **kw)
 
 
 @dataclass
@@ -120,6 +140,7 @@ def tiny_config(latent_size=16, max_batch=2):
 def from_model_dir(path, latent_size=64, max_batch=1):
     """Populates the config from a local HF Stable-Diffusion directory when its JSON files exist."""
     cfg = sd15_config(latent_size, max_batch)
+    cfg.text_len = None
 
     def _load(sub):
         p = os.path.join(path, sub)
@@ -150,10 +171,27 @@ def from_model_dir(path, latent_size=64, max_batch=1):
                   "max_position_embeddings", "hidden_act", "layer_norm_eps"):
             if k in t:
                 setattr(cfg.text, k, t[k])
+    cfg.text_len = cfg.text.max_position_embeddings
+    if v and "latent_channels" in v:
+        cfg.vae.latent_channels = v["latent_channels"]
+    if u:
+        cfg.unet.in_channels = u.get("in_channels", cfg.unet.in_channels)
+        cfg.unet.out_channels = u.get("out_channels", cfg.unet.out_channels)
     s = _load("scheduler/scheduler_config.json")
     if s:
         for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one",
                   "clip_sample", "prediction_type", "timestep_spacing"):
             if k in s:
                 setattr(cfg.scheduler, k, s[k])
+    # the engine implements the sampler the SD-1.x repos configure; anything else would run with silently wrong
+    # results, so it is refused
+    sc = cfg.scheduler
+    if sc.prediction_type != "epsilon":
+        raise NotImplementedError("scheduler prediction_type=%r: only epsilon-prediction models are built" % sc.prediction_type)
+    if sc.clip_sample:
+        raise NotImplementedError("scheduler clip_sample=true is not built (SD-1.x uses clip_sample=false)")
+    if sc.timestep_spacing != "leading":
+        raise NotImplementedError("scheduler timestep_spacing=%r: only 'leading' is built" % sc.timestep_spacing)
+    if sc.beta_schedule != "scaled_linear":
+        raise NotImplementedError("scheduler beta_schedule=%r: only 'scaled_linear' is built" % sc.beta_schedule)
     return cfg

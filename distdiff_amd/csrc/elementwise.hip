@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, const f
   s = wave_sum(s);
   if (lane == 0) y[(size_t)m * N + n] = s + (b ? b[n] : 0.f);
 }
+__global__ void add_rowvec_kernel(float* y, const float* v, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) y[i] += v[i % cols]; }
 __global__ void scale_rows_kernel(float* x, const float* s, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) x[i] *= s[0]; }
 
 // ---- f-2: stage before the loop (dataloader.py:633-661, 750-811) -----------------------------------------------
@@ -626,6 +627,9 @@ hipError_t launch_sub_scaled(const float* a, const float* g, float* out, size_t 
 }
 hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) { LAUNCH(f32_to_bf16_kernel, n, src, dst, n); }
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s) { LAUNCH(fill_kernel, n, dst, v, n); }
+hipError_t launch_add_rowvec_f32(float* y, const float* v, int rows, int cols, hipStream_t s) {
+  LAUNCH(add_rowvec_kernel, (size_t)rows * cols, y, v, rows, cols);
+}
 hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s) {
   LAUNCH(to_uint8_kernel, (size_t)B * H * W * C, nchw, hwc, B, C, H * W);
 }

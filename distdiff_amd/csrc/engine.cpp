@@ -65,7 +65,7 @@ struct ConvW {
   float* bias = nullptr;       // [Cout] (packed order for GEGLU) or null
   float* bias_table = nullptr; // [n_steps][Cout] per-timestep effective bias (resnet conv1 + time_emb_proj)
   // fp32 copies kept for the time-embedding tables
-  float* temb_w = nullptr; float* temb_b = nullptr; std::vector<float> conv_bias_host;
+  float* temb_w = nullptr; float* temb_b = nullptr;
 };
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 
@@ -234,6 +234,20 @@ struct dd_engine {
     hipFree(p);
   }
   std::vector<void*> sched_allocs;   // tables of the current schedule (replaced by the next dd_set_schedule)
+  // packed weights: every weight-derived device buffer in creation order (dd_packed_bytes / dd_export_packed / dd_import_packed)
+  int declared = 0;
+  bool shape_only = false;           // tensors were declared (shapes only): buffers are allocated, their content arrives by import
+  std::vector<std::pair<char*, size_t>> packed;
+  void* wupload(const void* host, size_t bytes) {
+    void* d = dmalloc(bytes, false);
+    packed.push_back({(char*)d, bytes});
+    if (!shape_only && bytes) {
+      if (!host) throw std::runtime_error("internal: weight upload without host data");
+      hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) throw std::runtime_error(std::string("weight upload failed: ") + hipGetErrorString(e));
+    }
+    return d;
+  }
   void* dmalloc(size_t bytes, bool zero = true) {
     void* p = nullptr;
     bytes = std::max<size_t>(bytes, 256);
@@ -257,6 +271,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // weight construction
 // ---------------------------------------------------------------------------------------------------
+// Every device buffer that holds weight-derived data goes through E->wupload(): it is registered, in creation order, in the engine's
+// packed-weight list (dd_packed_bytes / dd_export_packed / dd_import_packed), and an engine that only knows the tensor SHAPES
+// (dd_declare_tensor: a rank that will receive the packed buffers over RCCL) allocates it without packing anything on the host.
+
 // fp32 packing (guide program): w is [Cout][Cin/groups][KH][KW]
 ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, int groups,
                      bool need_bwd) {
@@ -265,53 +283,46 @@ ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, 
   for (int mode = 0; mode < (need_bwd ? 2 : 1); ++mode) {
     PackedConv& sh = mode ? cw->sb : cw->sf;
     sh = pack_conv_shape_f32(Cout, Cin, KH, KW, mode, groups);
-    std::vector<float> wp((size_t)sh.N * sh.K);
-    std::vector<int> tt(sh.ntaps);
-    pack_conv_weight_f32(w, Cout, Cin, KH, KW, pad, mode, groups, wp.data(), tt.data());
-    float* d = (float*)E->dmalloc(wp.size() * 4, false);
-    HIPCHK(hipMemcpy(d, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
-    int* t = (int*)E->dmalloc(tt.size() * 4, false);
-    HIPCHK(hipMemcpy(t, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> wp;
+    std::vector<int> tt;
+    if (!E->shape_only) {
+      wp.resize((size_t)sh.N * sh.K); tt.resize(sh.ntaps);
+      pack_conv_weight_f32(w, Cout, Cin, KH, KW, pad, mode, groups, wp.data(), tt.data());
+    }
+    float* d = (float*)E->wupload(wp.data(), (size_t)sh.N * sh.K * 4);
+    int* t = (int*)E->wupload(tt.data(), (size_t)sh.ntaps * 4);
     if (mode) { cw->wf_bwd = d; cw->tap_bwd = t; } else { cw->wf_fwd = d; cw->tap_fwd = t; }
   }
-  if (bias) {
-    cw->bias = (float*)E->dmalloc(Cout * 4, false);
-    HIPCHK(hipMemcpy(cw->bias, bias, Cout * 4, hipMemcpyHostToDevice));
-  }
+  if (bias || E->shape_only) cw->bias = (float*)E->wupload(bias, (size_t)Cout * 4);
   E->convs.push_back(std::move(cw));
   return E->convs.back().get();
 }
 
-ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, bool geglu,
-                     bool need_bwd) {
+// has_bias is passed explicitly: a shape-only engine has no host data to look at
+ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_bias, int Cout, int Cin, int KH, int KW, int pad,
+                     bool geglu, bool need_bwd) {
   auto cw = std::make_unique<ConvW>();
   cw->Cout = Cout; cw->Cin = Cin; cw->KH = KH; cw->KW = KW; cw->pad = pad; cw->geglu = geglu;
-  cw->sf = pack_conv_shape(Cout, Cin, KH, KW, 0);
-  {
-    std::vector<bf16_t> wp((size_t)cw->sf.N * cw->sf.K);
-    std::vector<int> tt(cw->sf.ntaps);
-    pack_conv_weight(w, Cout, Cin, KH, KW, pad, 0, geglu, wp.data(), tt.data());
-    cw->w_fwd = (bf16_t*)E->dmalloc(wp.size() * 2, false);
-    HIPCHK(hipMemcpy(cw->w_fwd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
-    cw->tap_fwd = (int*)E->dmalloc(tt.size() * 4, false);
-    HIPCHK(hipMemcpy(cw->tap_fwd, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+  for (int mode = 0; mode < (need_bwd ? 2 : 1); ++mode) {
+    PackedConv& sh = mode ? cw->sb : cw->sf;
+    sh = pack_conv_shape(Cout, Cin, KH, KW, mode);
+    std::vector<bf16_t> wp;
+    std::vector<int> tt;
+    if (!E->shape_only) {
+      wp.resize((size_t)sh.N * sh.K); tt.resize(sh.ntaps);
+      pack_conv_weight(w, Cout, Cin, KH, KW, pad, mode, geglu, wp.data(), tt.data());
+    }
+    bf16_t* d = (bf16_t*)E->wupload(wp.data(), (size_t)sh.N * sh.K * 2);
+    int* t = (int*)E->wupload(tt.data(), (size_t)sh.ntaps * 4);
+    if (mode) { cw->w_bwd = d; cw->tap_bwd = t; } else { cw->w_fwd = d; cw->tap_fwd = t; }
   }
-  if (need_bwd) {
-    cw->sb = pack_conv_shape(Cout, Cin, KH, KW, 1);
-    std::vector<bf16_t> wp((size_t)cw->sb.N * cw->sb.K);
-    std::vector<int> tt(cw->sb.ntaps);
-    pack_conv_weight(w, Cout, Cin, KH, KW, pad, 1, geglu, wp.data(), tt.data());
-    cw->w_bwd = (bf16_t*)E->dmalloc(wp.size() * 2, false);
-    HIPCHK(hipMemcpy(cw->w_bwd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
-    cw->tap_bwd = (int*)E->dmalloc(tt.size() * 4, false);
-    HIPCHK(hipMemcpy(cw->tap_bwd, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
-  }
-  if (bias) {
-    std::vector<float> b(Cout);
-    for (int n = 0; n < Cout; ++n) b[n] = bias[geglu ? geglu_perm(n, Cout / 2) : n];
-    cw->bias = (float*)E->dmalloc(Cout * 4, false);
-    HIPCHK(hipMemcpy(cw->bias, b.data(), Cout * 4, hipMemcpyHostToDevice));
-    cw->conv_bias_host.assign(bias, bias + Cout);
+  if (has_bias) {
+    std::vector<float> b;
+    if (!E->shape_only) {
+      b.resize(Cout);
+      for (int n = 0; n < Cout; ++n) b[n] = bias[geglu ? geglu_perm(n, Cout / 2) : n];
+    }
+    cw->bias = (float*)E->wupload(b.data(), (size_t)Cout * 4);
   }
   E->convs.push_back(std::move(cw));
   return E->convs.back().get();
@@ -322,9 +333,9 @@ ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& pref
   const HostTensor& w = E->get(model, prefix + ".weight");
   const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
   const int KH = w.shape.size() == 4 ? (int)w.shape[2] : 1, KW = w.shape.size() == 4 ? (int)w.shape[3] : 1;
-  const float* b = nullptr;
-  if (has_bias && E->has(model, prefix + ".bias")) b = E->get(model, prefix + ".bias").data.data();
-  return make_conv_raw(E, w.data.data(), b, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0);
+  const bool hb = has_bias && E->has(model, prefix + ".bias");
+  const float* b = hb ? E->get(model, prefix + ".bias").data.data() : nullptr;
+  return make_conv_raw(E, w.data.data(), b, hb, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0);
 }
 
 // several linears sharing the input, concatenated along Cout (fused QKV)
@@ -338,7 +349,7 @@ ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<s
     w.insert(w.end(), t.data.begin(), t.data.end());
     if (with_bias) { const HostTensor& bb = E->get(model, p + ".bias"); b.insert(b.end(), bb.data.begin(), bb.data.end()); }
   }
-  return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0);
+  return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, with_bias, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0);
 }
 
 // conv (no bias) followed by eval-mode BatchNorm, folded: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)
@@ -355,12 +366,15 @@ ConvW* make_conv_bn(dd_engine* E, const std::string& model, const std::string& c
   if (Cg < 1 || cin_total % Cg || Cout % (cin_total / Cg))
     throw std::runtime_error("guide conv " + conv + ": weight shape does not divide the input channels (groups)");
   const int groups = cin_total / Cg;
-  std::vector<float> wf(w.data.size()), bf(Cout);
-  const size_t per = (size_t)Cg * KH * KW;
-  for (int n = 0; n < Cout; ++n) {
-    const float sc = g.data[n] / sqrtf(var.data[n] + eps);
-    for (size_t i = 0; i < per; ++i) wf[n * per + i] = w.data[n * per + i] * sc;
-    bf[n] = be.data[n] - mu.data[n] * sc;
+  std::vector<float> wf, bf(Cout);
+  if (!E->shape_only) {
+    wf.resize(w.numel());
+    const size_t per = (size_t)Cg * KH * KW;
+    for (int n = 0; n < Cout; ++n) {
+      const float sc = g.data[n] / sqrtf(var.data[n] + eps);
+      for (size_t i = 0; i < per; ++i) wf[n * per + i] = w.data[n * per + i] * sc;
+      bf[n] = be.data[n] - mu.data[n] * sc;
+    }
   }
   return make_conv_f32(E, wf.data(), bf.data(), Cout, cin_total, KH, KW, pad, groups, E->cfg.enable_grad != 0);
 }
@@ -370,10 +384,8 @@ NormW* make_norm(dd_engine* E, const std::string& model, const std::string& pref
   const HostTensor& g = E->get(model, prefix + ".weight");
   const HostTensor& b = E->get(model, prefix + ".bias");
   nw->C = (int)g.shape[0];
-  nw->gamma = (float*)E->dmalloc(nw->C * 4, false);
-  nw->beta = (float*)E->dmalloc(nw->C * 4, false);
-  HIPCHK(hipMemcpy(nw->gamma, g.data.data(), nw->C * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(nw->beta, b.data.data(), nw->C * 4, hipMemcpyHostToDevice));
+  nw->gamma = (float*)E->wupload(g.data.data(), (size_t)nw->C * 4);
+  nw->beta = (float*)E->wupload(b.data.data(), (size_t)nw->C * 4);
   E->norms.push_back(std::move(nw));
   return E->norms.back().get();
 }
@@ -785,10 +797,8 @@ int build_resnet(Builder& b, const std::string& model, const std::string& p, int
     // per-timestep effective bias table is filled by dd_set_schedule from time_emb_proj
     const HostTensor& tw = E->get(model, p + ".time_emb_proj.weight");
     const HostTensor& tb = E->get(model, p + ".time_emb_proj.bias");
-    c1->temb_w = (float*)E->dmalloc(tw.data.size() * 4, false);
-    c1->temb_b = (float*)E->dmalloc(tb.data.size() * 4, false);
-    HIPCHK(hipMemcpy(c1->temb_w, tw.data.data(), tw.data.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c1->temb_b, tb.data.data(), tb.data.size() * 4, hipMemcpyHostToDevice));
+    c1->temb_w = (float*)E->wupload(tw.data.data(), tw.numel() * 4);
+    c1->temb_b = (float*)E->wupload(tb.data.data(), tb.numel() * 4);
     E->temb_convs.push_back(c1);
   }
   int h = b.gn(x, n1, G, eps, 1);
@@ -971,10 +981,8 @@ void build_text_encoder(dd_engine* E) {
   if (E->text_hidden != c.unet_cross_dim) throw std::runtime_error("text encoder width != UNet cross_attention_dim");
   const int heads = c.text_heads > 0 ? c.text_heads : 12;
   if (E->text_hidden % heads) throw std::runtime_error("text hidden size is not divisible by text_heads");
-  E->tok_emb = (float*)E->dmalloc(tok.data.size() * 4, false);
-  HIPCHK(hipMemcpy(E->tok_emb, tok.data.data(), tok.data.size() * 4, hipMemcpyHostToDevice));
-  E->pos_emb = (float*)E->dmalloc(pos.data.size() * 4, false);
-  HIPCHK(hipMemcpy(E->pos_emb, pos.data.data(), pos.data.size() * 4, hipMemcpyHostToDevice));
+  E->tok_emb = (float*)E->wupload(tok.data.data(), tok.numel() * 4);
+  E->pos_emb = (float*)E->wupload(pos.data.data(), pos.numel() * 4);
   const int Bt = 2 * c.max_batch, T = c.text_len, C = E->text_hidden;
   const float eps = c.text_eps > 0.f ? c.text_eps : 1e-5f;
   E->text_batch = Bt;
@@ -1184,9 +1192,55 @@ int dd_load_tensor(dd_engine* e, const char* model, const char* key, const float
   return DD_OK;
 }
 
+int dd_declare_tensor(dd_engine* e, const char* model, const char* key, int ndim, const int64_t* shape) {
+  if (!e || !model || !key || ndim < 1 || ndim > 4 || !shape) return DD_ERR_ARG;
+  if (e->finalized) { e->err = "dd_declare_tensor after dd_finalize_weights"; return DD_ERR_STATE; }
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  e->raw[std::string(model) + "/" + key] = std::move(t);
+  e->declared++;
+  return DD_OK;
+}
+
+size_t dd_packed_bytes(dd_engine* e) {
+  if (!e) return 0;
+  size_t n = 0;
+  for (auto& p : e->packed) n += rup_sz(p.second, 256);
+  return n;
+}
+
+// the packed weights as one virtual byte array (each buffer padded to 256 bytes): copy [offset, offset + bytes) to / from `buf`
+static int packed_copy(dd_engine* E, char* buf, size_t offset, size_t bytes, bool to_engine, hipStream_t s) {
+  DD_TRY(E, {
+    if (!E->finalized) throw std::runtime_error("dd_finalize_weights has not been called");
+    size_t pos = 0;
+    const size_t end = offset + bytes;
+    for (auto& p : E->packed) {
+      const size_t lo = std::max(pos, offset), hi = std::min(pos + p.second, end);
+      if (lo < hi) {
+        char* dev = p.first + (lo - pos);
+        char* b = buf + (lo - offset);
+        HIPCHK(hipMemcpyAsync(to_engine ? dev : b, to_engine ? b : dev, hi - lo, hipMemcpyDeviceToDevice, s));
+      }
+      pos += rup_sz(p.second, 256);
+      if (pos >= end) break;
+    }
+  });
+}
+int dd_export_packed(dd_engine* e, void* dst, size_t offset, size_t bytes, void* stream) {
+  if (!e || !dst) return DD_ERR_ARG;
+  return packed_copy(e, (char*)dst, offset, bytes, false, (hipStream_t)stream);
+}
+int dd_import_packed(dd_engine* e, const void* src, size_t offset, size_t bytes, void* stream) {
+  if (!e || !src) return DD_ERR_ARG;
+  return packed_copy(e, (char*)src, offset, bytes, true, (hipStream_t)stream);
+}
+
 int dd_finalize_weights(dd_engine* E) {
   if (!E) return DD_ERR_ARG;
   if (E->finalized) { E->err = "already finalized"; return DD_ERR_STATE; }
+  if (E->declared && E->declared != (int)E->raw.size()) { E->err = "dd_declare_tensor and dd_load_tensor cannot be mixed"; return DD_ERR_STATE; }
+  E->shape_only = E->declared > 0;
   DD_TRY(E, {
     const dd_config& c = E->cfg;
     build_unet(E);
@@ -1199,9 +1253,7 @@ int dd_finalize_weights(dd_engine* E) {
     // time embedding MLP weights (fp32, setup-time only)
     auto up = [&](const char* key) {
       const HostTensor& t = E->get("unet", key);
-      float* d = (float*)E->dmalloc(t.data.size() * 4, false);
-      HIPCHK(hipMemcpy(d, t.data.data(), t.data.size() * 4, hipMemcpyHostToDevice));
-      return d;
+      return (float*)E->wupload(t.data.data(), t.numel() * 4);
     };
     E->temb_w1 = up("time_embedding.linear_1.weight"); E->temb_b1 = up("time_embedding.linear_1.bias");
     E->temb_w2 = up("time_embedding.linear_2.weight"); E->temb_b2 = up("time_embedding.linear_2.bias");
@@ -1305,13 +1357,7 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
       cw->bias_table = (float*)E->dmalloc((size_t)n * cw->Cout * 4, false);
       E->sched_allocs.push_back(cw->bias_table);
       HIPCHK(launch_linear_f32(d_emb, cw->temb_w, cw->temb_b, cw->bias_table, n, cw->Cout, TE, 1, nullptr));
-      // + conv1.bias
-      HIPCHK(hipDeviceSynchronize());
-      std::vector<float> tab((size_t)n * cw->Cout);
-      HIPCHK(hipMemcpy(tab.data(), cw->bias_table, tab.size() * 4, hipMemcpyDeviceToHost));
-      for (int i = 0; i < n; ++i)
-        for (int o = 0; o < cw->Cout; ++o) tab[(size_t)i * cw->Cout + o] += cw->conv_bias_host.empty() ? 0.f : cw->conv_bias_host[o];
-      HIPCHK(hipMemcpy(cw->bias_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+      if (cw->bias) HIPCHK(launch_add_rowvec_f32(cw->bias_table, cw->bias, n, cw->Cout, nullptr));   // + conv1.bias
     }
     HIPCHK(hipDeviceSynchronize());
   });

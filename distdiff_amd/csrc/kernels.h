@@ -192,6 +192,8 @@ hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream
 // setup-time fp32 linear: y = act(x) W^T + b (time-embedding tables)
 hipError_t launch_linear_f32(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int silu_in, hipStream_t s);
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s);
+// y[r, c] += v[c]  (fp32 rows; setup-time: the per-timestep bias tables)
+hipError_t launch_add_rowvec_f32(float* y, const float* v, int rows, int cols, hipStream_t s);
 // (x/2+0.5).clamp(0,1)*255+0.5 -> uint8 HWC (output stage, generate_data.py:1227 + save_image quantisation)
 hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H, int W, hipStream_t s);
 

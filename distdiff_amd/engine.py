@@ -54,6 +54,11 @@ def _declare(l):
     l.dd_last_error.restype = C.c_char_p
     l.dd_load_tensor.argtypes = [vp, C.c_char_p, C.c_char_p, vp, i, C.POINTER(C.c_int64)]
     l.dd_finalize_weights.argtypes = [vp]
+    l.dd_declare_tensor.argtypes = [vp, C.c_char_p, C.c_char_p, i, C.POINTER(C.c_int64)]
+    l.dd_packed_bytes.argtypes = [vp]
+    l.dd_packed_bytes.restype = C.c_size_t
+    l.dd_export_packed.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    l.dd_import_packed.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
     l.dd_set_schedule.argtypes = [vp, vp, i, vp, i, f, C.POINTER(DDSamplerParams)]
     l.dd_set_prototypes.argtypes = [vp, vp, vp, i, i, i]
     l.dd_set_prompt.argtypes = [vp, vp, i, vp]
@@ -124,7 +129,11 @@ def _stream():
 class Engine:
     """One engine per device. Mirrors the objects the reference builds at generate_data.py:863-922, 1100-1125."""
 
-    def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0"):
+    def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0", layout=None):
+        """weights: {"unet" | "vae" | "guide" | "text": state dict} -- packed on this rank; or None with `layout` = the
+        `weight_layout()` of the rank that has them: the engine is then built from the tensor shapes alone and its packed weight
+        buffers are filled by `import_packed` (launcher.broadcast_packed_weights: one RCCL broadcast of the packed device buffers
+        instead of every process loading its own copy, scripts/exps/expand_diff.sh:19-24)."""
         self.cfg = cfg
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -132,14 +141,23 @@ class Engine:
         self._h = vp()
         cc = _to_c_config(cfg, enable_grad, max_guidance_period)
         self._chk(self.L.dd_create(C.byref(cc), C.byref(self._h)), "dd_create")
-        for model in ("unet", "vae", "guide", "text"):
-            for key, t in weights.get(model, {}).items():
-                if key.startswith("fc.") or key.endswith("num_batches_tracked"):
-                    continue
-                a = t.detach().float().contiguous().cpu()
-                shape = (C.c_int64 * a.dim())(*a.shape)
-                self._chk(self.L.dd_load_tensor(self._h, model.encode(), key.encode(), vp(a.data_ptr()), a.dim(), shape),
-                          "dd_load_tensor " + key)
+        if weights is not None:
+            self.layout = []
+            for model in ("unet", "vae", "guide", "text"):
+                for key, t in weights.get(model, {}).items():
+                    if key.startswith("fc.") or key.endswith("num_batches_tracked"):
+                        continue
+                    a = t.detach().float().contiguous().cpu()
+                    shape = (C.c_int64 * a.dim())(*a.shape)
+                    self._chk(self.L.dd_load_tensor(self._h, model.encode(), key.encode(), vp(a.data_ptr()), a.dim(), shape),
+                              "dd_load_tensor " + key)
+                    self.layout.append((model, key, tuple(a.shape)))
+        else:
+            assert layout is not None, "Engine needs weights or the layout of the rank that holds them"
+            self.layout = list(layout)
+            for model, key, shp in self.layout:
+                shape = (C.c_int64 * len(shp))(*shp)
+                self._chk(self.L.dd_declare_tensor(self._h, model.encode(), key.encode(), len(shp), shape), "dd_declare_tensor " + key)
         self._chk(self.L.dd_finalize_weights(self._h), "dd_finalize_weights")
         self.n_steps = 0
         self.B = cfg.max_batch
@@ -161,6 +179,20 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    # ---- packed weights (multi-GPU start-up) ---------------------------------------------------
+    def weight_layout(self):
+        return list(self.layout)
+
+    def packed_bytes(self):
+        return int(self.L.dd_packed_bytes(self._h))
+
+    def export_packed(self, buf, offset):
+        """Copies bytes [offset, offset + buf.numel()) of the packed weights into the device uint8 tensor `buf`."""
+        self._chk(self.L.dd_export_packed(self._h, _p(buf), offset, buf.numel(), _stream()), "dd_export_packed")
+
+    def import_packed(self, buf, offset):
+        self._chk(self.L.dd_import_packed(self._h, _p(buf), offset, buf.numel(), _stream()), "dd_import_packed")
 
     # ---- setup -------------------------------------------------------------------------------
     def set_schedule(self, timesteps, alphas_cumprod, final_alpha_cumprod, guidance_scale=7.5, gs=1.0, ls=1.0, rho=10.0,

@@ -324,31 +324,51 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     return written
 
 
-def build_engine(args):
-    from .config import from_model_dir, sd15_config, tiny_config
-    from .engine import Engine
-    from .model_utils import create_model
-    from .scheduler import DDIMSchedule
-    from .weights import load_guide_checkpoint, load_safetensors_dir, synthetic_weights
-    B = args.engine_batch or max(args.train_batch_size, 8)
+def load_config_and_weights(args, B):
+    """The model objects the reference builds at generate_data.py:863-922 and :1100-1104, as (EngineConfig, state dicts)."""
+    from .config import GUIDE_ARCHS, from_model_dir, guide_config, sd15_config, tiny_config
+    from .model_utils import SUPPORTED, create_model
+    from .weights import load_safetensors_dir, synthetic_weights
     latent = args.resolution // 8
     if args.synthetic:
         cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
-        weights = synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes, encoders=args.synthetic_encode)
-    else:
-        path = args.pretrained_model_name_or_path
-        if not os.path.isdir(path):
-            raise SystemExit("%s is not a local model directory (no network access here); pass a local Hugging Face layout with unet/ and "
-                             "vae/ safetensors, or use --synthetic N" % path)
-        cfg = from_model_dir(path, latent, B)
-        guide = create_model(args.arch, pretrained=False, num_classes=1, weight_path=args.encoder_weight_path)
-        weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": guide.state_dict(),
-                   "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder", ("model.safetensors",)).items()
-                            if "position_ids" not in k}}
+        if args.arch in GUIDE_ARCHS:                 # -a resnext50 / wideresnet50: same Bottleneck program, other widths / groups
+            for k, v in GUIDE_ARCHS[args.arch].items():
+                setattr(cfg.guide, k, v)
+            cfg.guide.arch = args.arch
+        return cfg, synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes, encoders=args.synthetic_encode)
+    path = args.pretrained_model_name_or_path
+    if not os.path.isdir(path):
+        raise SystemExit("%s is not a local model directory (no network access here); pass a local Hugging Face layout with unet/, vae/, "
+                         "text_encoder/, tokenizer/, scheduler/, or use --synthetic N" % path)
+    cfg = from_model_dir(path, latent, B)
+    arch = args.arch if (args.guidance_type or args.arch in SUPPORTED) else "resnet50"   # unguided runs never evaluate the guide
+    cfg.guide = guide_config(arch)
+    guide = create_model(arch, pretrained=False, num_classes=1, weight_path=args.encoder_weight_path if args.guidance_type else None)
+    weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": guide.state_dict(),
+               "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder").items() if "position_ids" not in k}}
+    return cfg, weights
+
+
+def build_engine(args, device=None, distributed=False):
+    from .engine import Engine
+    from .scheduler import DDIMSchedule
+    B = args.engine_batch or max(args.train_batch_size, 8)
     guided = bool(args.guidance_type)
     # transform_guidance differentiates through P chained steps (P activation stashes); direct_guidance one step at a time
     stash = max(1, args.guidance_period) if args.guidance_type == "transform_guidance" else 1
-    eng = Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=args.device or "cuda:0")
+    dev = device or args.device or "cuda:0"
+
+    def make_engine(cfg, weights, layout):
+        return Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=dev, layout=layout)
+
+    if distributed:
+        # rank 0 loads + packs once; the packed device buffers go to the other ranks in one RCCL broadcast (launcher.py)
+        from .launcher import build_engine_distributed
+        cfg, eng = build_engine_distributed(lambda: load_config_and_weights(args, B), make_engine)
+    else:
+        cfg, weights = load_config_and_weights(args, B)
+        eng = make_engine(cfg, weights, None)
     sched = DDIMSchedule(cfg.scheduler)
     ts = sched.set_timesteps(args.steps)
     targets = (args.optimize_targets or "").split("-")
@@ -359,17 +379,33 @@ def build_engine(args):
 
 
 def main(argv=None):
+    import time
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO)
+    if args.guidance_type not in (None, "transform_guidance", "direct_guidance"):
+        raise SystemExit("unknown --guidance_type %r" % args.guidance_type)
+    from .model_utils import SUPPORTED
+    if args.guidance_type and args.arch not in SUPPORTED and not args.synthetic:
+        raise SystemExit("guide arch %r is not built (built: %s; SURVEY.md section 8f-4)" % (args.arch, ", ".join(SUPPORTED)))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the in-process fan-out that replaces single_exp.sh / expand_diff.sh's one shell per GPU: start the ranks before any GPU call
+        from .launcher import spawn_ranks
+        return spawn_ranks(args.gpus, argv)
+    distributed = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    rank, world, device = 0, 1, None
+    if distributed:
+        from .launcher import init_distributed
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(torch.device(device))
+        rank, world = init_distributed(device)
+        args.split, args.total_split = rank, world          # the reference's --split / --total_split, one per rank
     if args.seed is not None:
         import random
         import numpy as np
         random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)   # accelerate.set_seed, :861
-    if args.guidance_type not in (None, "transform_guidance", "direct_guidance"):
-        raise SystemExit("unknown --guidance_type %r" % args.guidance_type)
-    if args.guidance_type and args.arch != "resnet50" and not args.synthetic:
-        raise SystemExit("guide arch %r: only resnet50 is built (SURVEY.md section 8f-4)" % args.arch)
-    cfg, eng, sched = build_engine(args)
+    cfg, eng, sched = build_engine(args, device=device, distributed=distributed)
+    dev = eng.device
     if args.synthetic:
         if args.synthetic_encode:
             ds = ExpansionDataset.synthetic_encoded(cfg, eng, args.synthetic, args.synthetic_classes, seed=args.seed or 0)
@@ -381,20 +417,38 @@ def main(argv=None):
             Pc = torch.randn(args.synthetic_classes, D, generator=g)
             Pg = torch.randn(args.synthetic_classes, args.K, D, generator=g)
     else:
+        if distributed and rank != 0:
+            import torch.distributed as dist
+            dist.barrier()                                  # rank 0 fills the latent cache first, the others then read it
         ds = ExpansionDataset.from_dataset(args, cfg, eng)
+        if distributed and rank == 0:
+            import torch.distributed as dist
+            dist.barrier()
         if args.guidance_type:
             from .prototypes import extract_prototypes_with_encoder
             assert args.encoder_weight_path and os.path.exists(args.encoder_weight_path)       # :1108
-            Pc, Pg = extract_prototypes_with_encoder(args, eng, ds)
+            Pc, Pg = extract_prototypes_with_encoder(args, eng, ds, rank=rank, world=world)
     if args.guidance_type:
         Pc = Pc / Pc.norm(dim=-1, keepdim=True)                            # re-normalisation, :1115-1116, 1121-1122
         Pg = Pg / Pg.norm(dim=-1, keepdim=True)
-        print("optimize strategy: %s, target: %s, learning rate: %s" % (args.guidance_type, args.optimize_targets, args.rho))
+        if rank == 0:
+            print("optimize strategy: %s, target: %s, learning rate: %s" % (args.guidance_type, args.optimize_targets, args.rho))
         eng.set_prototypes(Pc, Pg)
+    t0 = time.time()
     n = run_expansion(args, eng, sched, ds)
     torch.cuda.synchronize()
-    log.info("wrote %d images under %s", n, args.output_dir)
-    eng.close()
+    dt = time.time() - t0
+    log.info("rank %d/%d wrote %d images under %s in %.1f s", rank, world, n, args.output_dir, dt)
+    if distributed:
+        from .launcher import reduce_run_stats
+        import torch.distributed as dist
+        total, tmax = reduce_run_stats(n, dt, device=dev)
+        if rank == 0:
+            log.info("node total: %d images in %.1f s = %.2f images/s on %d GPUs", total, tmax, total / max(tmax, 1e-9), world)
+        eng.close()
+        dist.destroy_process_group()
+    else:
+        eng.close()
     return 0
 
 

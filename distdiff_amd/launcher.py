@@ -1,11 +1,20 @@
-"""Multi-GPU launcher pieces: the reference's shard function and the RCCL weight broadcast.
+"""The N-rank launcher of the expansion step.
 
-The reference fans out one OS process per GPU with `--split k --total_split N` (scripts/exps/expand_diff.sh:19-24,
-generate_data.py:1003-1009) and every process loads its own copy of the weights from disk. Here rank 0 loads
-(or synthesises) the weights once and broadcasts them over RCCL/xGMI; the unit of work (train image i,
-expand index j) shards with the reference's own partition function and needs no data-path collective.
+The reference fans out one OS process per GPU by hand, `CUDA_VISIBLE_DEVICES=k python generate_data.py --split k --total_split N`
+(single_exp.sh:4-8, scripts/exps/expand_diff.sh:19-24), and every process loads its own copy of the weights from disk and repeats the
+prototype extraction over the whole training set.  Here `generate_data.py --gpus N` (or `expand_diff.sh <EXPAND_NUM>`) starts N ranks,
+one per GPU, BEFORE any GPU call; rank 0 loads and packs the weights once and broadcasts the PACKED device buffers (bf16 MFMA layouts
++ fp32 guide / norm / embedding tables, ~2.4 GB for SD-1.x) over RCCL/xGMI in ~1 GiB buckets -- few, large collectives, because an
+xGMI ring is per-link bound -- ; prototype features are computed on per-rank shards and all-gathered; the units of work
+(train image i, expand index j) shard with the reference's own partition function (generate_data.py:1003-1007) and need no
+collective on the data path; image counts and elapsed time are all-reduced at the end for the node-level images/s.
 """
 import math
+import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 
@@ -18,53 +27,144 @@ def shard_range(total, total_split, split):
     return list(range(per * split, per * (split + 1)))
 
 
-def _layout(weights):
-    return [(m, k, tuple(t.shape)) for m in ("unet", "vae", "guide") for k, t in sorted(weights[m].items())]
+# ------------------------------------------------------------------------------------------------
+# process fan-out
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def broadcast_weights(weights, cfg, src=0, device=None, bucket_bytes=1 << 30, group=None):
-    """Broadcasts the state dicts from `src` to every rank in ~1 GiB flat fp32 buckets (few, large collectives:
-    xGMI ring/tree broadcasts are per-link bound, ~1.9 GB total for SD-1.x). Works on gloo (CPU tests) and nccl (=RCCL)."""
+def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None):
+    """Starts `n` worker processes of the CLI (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
+    127.0.0.1) and waits for them; returns the largest exit code.  The parent never touches the GPU."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, "-m", module] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    return rc
+
+
+def init_distributed(device=None):
+    """Joins the process group when launched with RANK/WORLD_SIZE set (by spawn_ranks or torchrun): nccl (= RCCL) on a GPU,
+    gloo on the CPU.  Returns (rank, world)."""
+    import torch.distributed as dist
+    if "RANK" not in os.environ:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device is not None and torch.device(device).type == "cuda":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo")
+    return dist.get_rank(), dist.get_world_size()
+
+
+# ------------------------------------------------------------------------------------------------
+# weights: one load + pack on rank 0, one broadcast of the packed device buffers
+# ------------------------------------------------------------------------------------------------
+def broadcast_object(obj, src=0, group=None):
+    import torch.distributed as dist
+    box = [obj if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def broadcast_packed_weights(engine, src=0, bucket_bytes=1 << 30, group=None, device=None):
+    """Broadcasts the packed weight buffers of rank `src`'s engine into every other rank's (shape-built) engine through a device
+    staging bucket: export -> dist.broadcast -> import.  Returns the number of bytes moved."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
-    meta = [_layout(weights)] if rank == src else [None]
-    dist.broadcast_object_list(meta, src=src, group=group)
-    layout = meta[0]
-    backend = dist.get_backend(group)
-    dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
-    out = {"unet": {}, "vae": {}, "guide": {}}
-    bucket, size = [], 0
-
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
-            return
-        n = sum(int(torch.tensor(s).prod()) if len(s) else 1 for _, _, s in bucket)
-        flat = torch.empty(n, dtype=torch.float32, device=dev)
+    total = engine.packed_bytes()
+    sizes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(sizes, total, group=group)
+    if len(set(sizes)) != 1:
+        raise RuntimeError("packed weight layouts differ across ranks: %s" % sizes)
+    dev = device if device is not None else getattr(engine, "device", torch.device("cpu"))
+    bucket = torch.empty(min(bucket_bytes, max(total, 1)), dtype=torch.uint8, device=dev)
+    off = 0
+    while off < total:
+        n = min(bucket.numel(), total - off)
+        view = bucket[:n]
         if rank == src:
-            off = 0
-            for m, k, s in bucket:
-                t = weights[m][k].reshape(-1).float()
-                flat[off:off + t.numel()] = t.to(dev)
-                off += t.numel()
-        dist.broadcast(flat, src=src, group=group)
-        host = flat.cpu()
-        off = 0
-        for m, k, s in bucket:
-            cnt = 1
-            for d in s:
-                cnt *= d
-            out[m][k] = host[off:off + cnt].reshape(s).clone()
-            off += cnt
-        bucket, size = [], 0
+            engine.export_packed(view, off)
+        dist.broadcast(view, src=src, group=group)
+        if rank != src:
+            engine.import_packed(view, off)
+        off += n
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return total
 
-    for m, k, s in layout:
-        cnt = 1
-        for d in s:
-            cnt *= d
-        if size + cnt * 4 > bucket_bytes and bucket:
-            flush()
-        bucket.append((m, k, s))
-        size += cnt * 4
-    flush()
+
+def build_engine_distributed(make_cfg_and_weights, make_engine, src=0, group=None):
+    """rank `src`: (cfg, weights) = make_cfg_and_weights(); engine = make_engine(cfg, weights, None).
+    other ranks: receive (cfg, layout) and build engine = make_engine(cfg, None, layout) from the shapes; then one broadcast of the
+    packed buffers.  Returns (cfg, engine)."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    if rank == src:
+        cfg, weights = make_cfg_and_weights()
+        eng = make_engine(cfg, weights, None)
+        del weights
+        broadcast_object((cfg, eng.weight_layout()), src, group)
+    else:
+        cfg, layout = broadcast_object(None, src, group)
+        eng = make_engine(cfg, None, layout)
+    t0 = time.time()
+    nbytes = broadcast_packed_weights(eng, src, group=group)
+    if rank == src:
+        print("broadcast %.2f GB of packed weights to %d ranks in %.2f s" % (nbytes / 1e9, dist.get_world_size(group), time.time() - t0),
+              flush=True)
+    return cfg, eng
+
+
+def broadcast_tensors(tensors, src=0, device=None, group=None):
+    """Small fp32 tensors (prototypes, per-class text embeddings) from `src` to every rank, through the device for nccl."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    meta = broadcast_object([tuple(t.shape) for t in tensors] if rank == src else None, src, group)
+    dev = device if (dist.get_backend(group) == "nccl" and device is not None) else torch.device("cpu")
+    out = []
+    for i, shp in enumerate(meta):
+        t = tensors[i].float().to(dev).contiguous() if rank == src else torch.empty(shp, dtype=torch.float32, device=dev)
+        dist.broadcast(t, src=src, group=group)
+        out.append(t.cpu())
     return out
+
+
+def all_gather_rows(rows, device=None, group=None):
+    """Row-wise all-gather of per-rank fp32 matrices [n_r, D] with different n_r, in rank order (prototype features, f-1)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, int(rows.shape[0]), group=group)
+    dev = device if (dist.get_backend(group) == "nccl" and device is not None) else torch.device("cpu")
+    D = rows.shape[1]
+    nmax = max(counts)
+    pad = torch.zeros(nmax, D, dtype=torch.float32, device=dev)
+    pad[:rows.shape[0]] = rows.float().to(dev)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c].cpu() for p, c in zip(parts, counts)])
+
+
+def reduce_run_stats(images, seconds, device=None, group=None):
+    """End of run: total images (sum) and wall time (max over ranks) -> node-level images/s."""
+    import torch.distributed as dist
+    dev = device if (dist.get_backend(group) == "nccl" and device is not None) else torch.device("cpu")
+    n = torch.tensor([float(images)], dtype=torch.float64, device=dev)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(n.item()), float(t.item())

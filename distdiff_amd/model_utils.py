@@ -1,13 +1,17 @@
 """Guide-model plugin surface of the reference (model_utils.py:43-104): `create_model(...)` returns an object with
 `encode_image(x[B,3,S,S]) -> [B,D]` (= forward_features -> global average pool -> flatten, model_utils.py:29-41),
 `forward(x) -> logits`, `.eval() / .float() / .to() / .cuda()`, and loads `{'state_dict': ...}` checkpoints with an optional
-`module.` prefix (model_utils.py:89-101). The arithmetic runs in the engine's ResNet-50 program (BN folded, bf16 MFMA).
-Only resnet50 is built (SURVEY.md section 8f-4 lists the other four architectures as next rows)."""
+`module.` prefix (model_utils.py:89-101). The arithmetic runs in the engine's guide program (BN folded, exact fp32 on v_mfma_f32_32x32x2_f32, guide_f32.hip).
+Built: the three timm Bottleneck networks of the reference -- resnet50 (model_utils.py:47-55), resnext50 = resnext50_32x4d (:56-63,
+grouped 3x3 convolutions) and wideresnet50 = wide_resnet50_2 (:72-79); the engine reads widths and groups from the weight shapes.
+mobilenetv2 (:64-71) and open_clip_vit_b32 (:80-87) are different network families and raise NotImplementedError."""
 import torch
 
 from .weights import load_guide_checkpoint, synthetic_guide
 
-SUPPORTED = ("resnet50",)
+from .config import GUIDE_ARCHS
+
+SUPPORTED = tuple(GUIDE_ARCHS)
 
 
 class GuideModel:
@@ -43,8 +47,11 @@ class GuideModel:
         return self
 
     def encode_image(self, x, pooling="avg"):
+        if pooling not in ("avg", "max"):
+            raise ValueError("Unsupported pooling type. Please use 'avg' or 'max'.")      # model_utils.py:36-37
         if pooling != "avg":
-            raise ValueError("Unsupported pooling type. Only 'avg' is built in the HIP engine.")
+            raise NotImplementedError("pooling='max' is not wired into the engine (the expansion path only ever uses the default "
+                                      "'avg', generate_data.py:705, :746; dataloader.py:676)")
         if self._engine is None:
             raise RuntimeError("GuideModel is not bound to an Engine (there is no CPU fallback): call .bind(engine)")
         B = self._engine.B
@@ -69,9 +76,13 @@ def create_model(model_name, num_classes=1000, pretrained=False, class_names=Non
                  weight_path=None, cfg=None):
     print("=> creating model '{}'".format(model_name))
     if model_name not in SUPPORTED:
-        raise NotImplementedError("guide arch %r is not built yet (resnet50 only; SURVEY.md section 8f-4)" % model_name)
-    from .config import sd15_config
-    sd = synthetic_guide(cfg or sd15_config(), seed=0, num_classes=num_classes)   # shapes of timm resnet50 + fc(num_classes)
+        raise NotImplementedError("guide arch %r is not built (built: %s; mobilenetv2 and open_clip_vit_b32 are other network "
+                                  "families, SURVEY.md section 8f-4)" % (model_name, ", ".join(SUPPORTED)))
+    from .config import guide_config, sd15_config
+    if cfg is None:
+        cfg = sd15_config()
+        cfg.guide = guide_config(model_name)
+    sd = synthetic_guide(cfg, seed=0, num_classes=num_classes)   # shapes of the timm network + fc(num_classes)
     model = GuideModel(model_name, sd, num_classes)
     if pretrained:
         model.load_state_dict(torch.load("save/%s_imagenet1k.pth" % model_name, map_location="cpu"), strict=False)

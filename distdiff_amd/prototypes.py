@@ -31,12 +31,19 @@ def prototypes_from_features(feats, targets, num_classes, K):
     return np.array(glob), np.array(loc)
 
 
-def extract_prototypes_with_encoder(args, engine, ds, batch_size=64):
+def extract_prototypes_with_encoder(args, engine, ds, batch_size=64, rank=0, world=1):
+    """dataloader.py:734-747.  With world > 1 every rank encodes a contiguous shard of the training images and the features are
+    all-gathered (rank order = dataset order), instead of every process repeating the whole pass as the reference's fan-out does;
+    the clustering is deterministic, so every rank then derives identical prototypes."""
     size = engine.cfg.guide.input_size
     feats = []
     B = engine.B
-    for i in range(0, len(ds), B):
-        paths = ds.image_paths[i:i + B]
+    mine = list(range(len(ds)))
+    if world > 1:
+        from .launcher import shard_range
+        mine = [i for i in shard_range(len(ds), world, rank) if i < len(ds)]
+    for i0 in range(0, len(mine), B):
+        paths = [ds.image_paths[i] for i in mine[i0:i0 + B]]
         x = torch.stack([_load_image(p, size) for p in paths])
         n = x.shape[0]
         if n < B:
@@ -44,6 +51,11 @@ def extract_prototypes_with_encoder(args, engine, ds, batch_size=64):
         f = engine.guide_encode(x.to(engine.device))[:n].float()
         f = f / f.norm(dim=-1, keepdim=True)                                       # dataloader.py:677
         feats.append(f.cpu())
-    feats = torch.cat(feats).numpy()
+    D = engine.cfg.guide.feature_dim
+    feats = torch.cat(feats) if feats else torch.zeros(0, D)
+    if world > 1:
+        from .launcher import all_gather_rows
+        feats = all_gather_rows(feats, device=engine.device)
+    feats = feats.numpy()
     g, l = prototypes_from_features(feats, ds.targets.numpy(), len(ds.class_names), args.K)
     return torch.from_numpy(g), torch.from_numpy(l)

@@ -228,11 +228,12 @@ def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
         for bi in range(nb):
             p = "layer%d.%d" % (li + 1, bi)
             out = planes * g.expansion
-            b.conv(p + ".conv1", planes, inp, 1, bias=False)
-            b.bn(p + ".bn1", planes)
-            b.conv(p + ".conv2", planes, planes, 3, bias=False)
-            b.bn(p + ".bn2", planes)
-            b.conv(p + ".conv3", out, planes, 1, bias=False)
+            width = g.width(planes)              # timm Bottleneck: resnext50_32x4d / wide_resnet50_2 widen (and group) conv2
+            b.conv(p + ".conv1", width, inp, 1, bias=False)
+            b.bn(p + ".bn1", width)
+            b.conv(p + ".conv2", width, width // g.cardinality, 3, bias=False)
+            b.bn(p + ".bn2", width)
+            b.conv(p + ".conv3", out, width, 1, bias=False)
             b.bn(p + ".bn3", out)
             if bi == 0 and (inp != out or li > 0):
                 b.conv(p + ".downsample.0", out, inp, 1, bias=False)
@@ -252,13 +253,40 @@ def synthetic_weights(cfg: EngineConfig, seed=0, num_classes=100, encoders=False
     return w
 
 
-def load_safetensors_dir(model_dir, sub, names=("diffusion_pytorch_model.safetensors",)):
-    from safetensors.torch import load_file
+_VAE_LEGACY = (("query", "to_q"), ("key", "to_k"), ("value", "to_v"), ("proj_attn", "to_out.0"))
+
+
+def normalize_vae_keys(sd):
+    """The published SD-1.x AutoencoderKL checkpoints (CompVis v1-4, runwayml v1-5, sd-vae-ft-mse) name the mid-block attention
+    projections `query / key / value / proj_attn`; diffusers renames them to `to_q / to_k / to_v / to_out.0` when it loads them
+    (generate_data.py:912-916 goes through that loader).  Same rename here, plus 1x1-conv-shaped projection weights squeezed to 2-D."""
+    out = {}
+    for k, v in sd.items():
+        if ".attentions." in k:
+            for old, new in _VAE_LEGACY:
+                k = k.replace(".%s." % old, ".%s." % new)
+            if k.endswith(".weight") and v.dim() == 4 and v.shape[2] == v.shape[3] == 1 and ".group_norm." not in k:
+                v = v[:, :, 0, 0]
+        out[k] = v
+    return out
+
+
+def load_safetensors_dir(model_dir, sub, names=("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors",
+                                                 "model.safetensors", "diffusion_pytorch_model.bin", "pytorch_model.bin")):
+    """State dict of one sub-model of a local Hugging Face directory (`unet/`, `vae/`, `text_encoder/`): safetensors first, the
+    torch `.bin` pickles older repos ship otherwise.  Keys are the diffusers / transformers names the engine consumes."""
     for n in names:
         p = os.path.join(model_dir, sub, n)
-        if os.path.exists(p):
-            return {k: v.float() for k, v in load_file(p).items()}
-    raise FileNotFoundError("no safetensors under %s/%s" % (model_dir, sub))
+        if not os.path.exists(p):
+            continue
+        if n.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(p)
+        else:
+            sd = torch.load(p, map_location="cpu", weights_only=True)
+        sd = {k: v.float() for k, v in sd.items()}
+        return normalize_vae_keys(sd) if sub == "vae" else sd
+    raise FileNotFoundError("no weights under %s/%s (looked for %s)" % (model_dir, sub, ", ".join(names)))
 
 
 def load_guide_checkpoint(path):

@@ -103,6 +103,16 @@ const char* dd_last_error(dd_engine* e);
 /* model: "unet" | "vae" | "guide" | "text"; key: Hugging Face / timm state-dict key; data: HOST fp32 */
 int dd_load_tensor(dd_engine* e, const char* model, const char* key, const float* data, int ndim, const int64_t* shape);
 int dd_finalize_weights(dd_engine* e);
+/* Multi-GPU start-up (replaces every process of scripts/exps/expand_diff.sh:19-24 loading its own copy from disk): rank 0 loads and
+ * finalizes as above; every other rank DECLARES the same tensors (shapes only, no data), finalizes -- the op graph and every packed
+ * weight buffer are built from the shapes alone, in the same order -- and then receives the packed buffers (bf16 MFMA layouts, fp32
+ * guide / norm / embedding tables) through its own device staging buffer, e.g. an RCCL broadcast over xGMI.  The packed weights are
+ * addressed as ONE virtual byte array of dd_packed_bytes() bytes; export / import copy the range [offset, offset + bytes) between it
+ * and a caller-owned DEVICE buffer on the given stream. */
+int dd_declare_tensor(dd_engine* e, const char* model, const char* key, int ndim, const int64_t* shape);
+size_t dd_packed_bytes(dd_engine* e);
+int dd_export_packed(dd_engine* e, void* dst, size_t offset, size_t bytes, void* stream);
+int dd_import_packed(dd_engine* e, const void* src, size_t offset, size_t bytes, void* stream);
 
 /* timesteps: host int32[n] (descending, e.g. 981..1); alphas_cumprod: host float[num_train]; */
 int dd_set_schedule(dd_engine* e, const int* timesteps, int n, const float* alphas_cumprod, int num_train_timesteps,

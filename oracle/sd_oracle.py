@@ -317,7 +317,8 @@ class GuideOracle:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 sc = x
                 o = F.relu(self._bn(F.conv2d(x, sd[p + ".conv1.weight"]), p + ".bn1"))
-                o = F.relu(self._bn(F.conv2d(o, sd[p + ".conv2.weight"], stride=stride, padding=1), p + ".bn2"))
+                w2 = sd[p + ".conv2.weight"]         # timm Bottleneck: groups = cardinality (resnext50_32x4d), 1 otherwise
+                o = F.relu(self._bn(F.conv2d(o, w2, stride=stride, padding=1, groups=o.shape[1] // w2.shape[1]), p + ".bn2"))
                 o = self._bn(F.conv2d(o, sd[p + ".conv3.weight"]), p + ".bn3")
                 if (p + ".downsample.0.weight") in sd:
                     sc = self._bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), p + ".downsample.1")

@@ -135,3 +135,77 @@ def test_prototype_extraction_from_image_files(hip_lib, tmp_path):
     for c in range(2):
         d = np.linalg.norm(Pg[c].numpy()[:, None] - l_ref[c][None], axis=-1)
         assert min(d[0, 0] + d[1, 1], d[0, 1] + d[1, 0]) < 1e-3 * np.linalg.norm(l_ref[c])
+
+
+def _write_tokenizer(d):
+    """A byte-level CLIP tokenizer without merges: every character is a token (vocab.json + merges.txt as CLIPTokenizer expects)."""
+    import json
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    os.makedirs(d)
+    json.dump(vocab, open(os.path.join(d, "vocab.json"), "w"))
+    open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"model_max_length": 13, "bos_token": "<|startoftext|>", "eos_token": "<|endoftext|>", "unk_token": "<|endoftext|>",
+               "pad_token": "<|endoftext|>"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    return len(vocab)
+
+
+def test_cli_on_a_model_directory_and_image_files(hip_lib, tmp_path, monkeypatch):
+    """The NON-synthetic product path end to end: a local Hugging Face-layout model directory (config.json + safetensors with the real
+    key names, legacy VAE attention names, tokenizer files), a reference-format guide checkpoint (`module.` prefix, real ResNet-50
+    shapes) and a 2-class tree of JPEG files -> from_model_dir + load_safetensors_dir + create_model(weight_path) + tokenizer + HIP text
+    encoder + HIP VAE encoder (latent cache written) + prototype extraction + transform-guided expansion -> PNG files; a second run
+    resumes from the files and the latent cache."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distdiff_amd import generate_data as G
+    from distdiff_amd.config import TextConfig, guide_config, sd15_config, tiny_config
+    from distdiff_amd.weights import synthetic_guide, synthetic_weights
+    from test_checkpoints import write_model_dir
+    monkeypatch.chdir(tmp_path)
+    model = str(tmp_path / "sd-tiny")
+    cfg = tiny_config(max_batch=4)
+    V = _write_tokenizer(os.path.join(model, "tokenizer"))
+    cfg.text = TextConfig(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                          max_position_embeddings=13)
+    write_model_dir(model, cfg, synthetic_weights(cfg, seed=0, num_classes=2, encoders=True))
+    gcfg = sd15_config()
+    gcfg.guide = guide_config("resnet50")
+    ck = str(tmp_path / "model_best.pth.tar")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in synthetic_guide(gcfg, seed=1, num_classes=2).items()}, "acc": 0,
+                "best_acc": 0, "optimizer": {}}, ck)
+    rng = np.random.RandomState(0)
+    for c in ("cat_a", "dog_b"):
+        d = tmp_path / "data" / "toy" / "train" / c
+        d.mkdir(parents=True)
+        for i in range(3):
+            Image.fromarray(rng.randint(0, 255, (150 + 10 * i, 140 + 20 * i, 3), dtype=np.uint8)).save(str(d / ("im%d.jpg" % i)), quality=90)
+    out = str(tmp_path / "out")
+    argv = ["--pretrained_model_name_or_path", model, "-d", "toy", "-a", "resnet50", "--encoder_weight_path", ck, "--data_root",
+            str(tmp_path / "data"), "--output_dir", out, "--resolution", "128", "--steps", "10", "--strength", "0.5", "--guidance_type",
+            "transform_guidance", "--guidance_step", "4", "--guidance_period", "2", "--optimize_targets", "global_prototype-local_prototype",
+            "--K", "2", "--train_batch_size", "1", "--engine_batch", "4", "--num_images_per_prompt", "2", "--constraint_value", "0.2",
+            "--offset_noise"]
+    assert G.main(argv) == 0
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
+    assert len(files) == 12 and os.path.basename(os.path.dirname(files[0])) == "cat a"      # `_` -> ' ' in the class directory (:1232)
+    im = np.asarray(Image.open(files[0]))
+    assert im.shape == (128, 128, 3) and im.std() > 1.0
+    cache = os.path.join("save", "vae_embedding", "toy", model.replace("/", "--"), "image_latents.pt")
+    assert os.path.exists(cache) and len(torch.load(cache)) == 6
+    mt = {f: os.path.getmtime(f) for f in files}
+    os.remove(files[3])
+    assert G.main(argv) == 0                                 # resume: only the missing (batch, expand index) group is regenerated
+    assert os.path.exists(files[3]) and all(os.path.getmtime(f) == mt[f] for f in files if f != files[3])

@@ -322,3 +322,42 @@ def test_config1_sd15_shapes_256px_guidance_off_vs_oracle(hip_lib):
     psnr = 10 * torch.log10(1.0 / (err ** 2).mean()).item()
     assert float(err.max()) < 0.2 and psnr > 28.0, (float(err.max()), psnr)
     eng.close()
+
+
+def test_packed_weights_export_import(hip_lib, fx):
+    """Multi-GPU start-up path (launcher.build_engine_distributed) on one device: an engine built from the tensor SHAPES alone
+    (dd_declare_tensor) receives the packed weight buffers of a loaded engine (dd_export_packed -> dd_import_packed, in ragged buckets)
+    and then produces bitwise identical results, UNet / VAE / guide / text encoder / time-embedding tables included."""
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    cfg = tiny_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=5, encoders=True)
+    a = Engine(cfg, w, enable_grad=True, max_guidance_period=2)
+    b = Engine(cfg, None, enable_grad=True, max_guidance_period=2, layout=a.weight_layout())
+    total = a.packed_bytes()
+    assert total == b.packed_bytes() and total > 1 << 20
+    off, step = 0, 1000003                      # deliberately not aligned to any buffer boundary
+    while off < total:
+        n = min(step, total - off)
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        a.export_packed(buf, off)
+        b.import_packed(buf, off)
+        off += n
+    torch.cuda.synchronize()
+    sched = DDIMSchedule(cfg.scheduler)
+    ts = sched.set_timesteps(fx["n_steps"])
+    first = fx["timesteps"].tolist().index(fx["guide_timesteps"][0])
+    outs = []
+    for eng in (a, b):
+        eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_period=2)
+        eng.set_prototypes(fx["Pc"], fx["Pg"])
+        eng.set_prompt(torch.cat([fx["negative_embeds"], fx["prompt_embeds"]]).cuda())
+        z, score, gz0 = eng.transform_guidance(fx["z"], fx["targets"], fx["e"], fx["b"], first, 2)
+        ids = torch.arange(2 * cfg.text_len).reshape(2, cfg.text_len) % cfg.text.vocab_size
+        img = torch.linspace(-1, 1, 2 * 3 * (8 * cfg.latent_size) ** 2).reshape(2, 3, 8 * cfg.latent_size, 8 * cfg.latent_size)
+        outs.append((z, score, gz0, eng.text_encode(ids), eng.vae_encode(img), eng.decode(z)))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    a.close(); b.close()
