@@ -197,7 +197,7 @@ def test_cli_on_a_model_directory_and_image_files(hip_lib, tmp_path, monkeypatch
             str(tmp_path / "data"), "--output_dir", out, "--resolution", "128", "--steps", "10", "--strength", "0.5", "--guidance_type",
             "transform_guidance", "--guidance_step", "4", "--guidance_period", "2", "--optimize_targets", "global_prototype-local_prototype",
             "--K", "2", "--train_batch_size", "1", "--engine_batch", "4", "--num_images_per_prompt", "2", "--constraint_value", "0.2",
-            "--offset_noise"]
+            "--offset_noise", "--total_split", "1", "--split", "0"]
     assert G.main(argv) == 0
     files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
     assert len(files) == 12 and os.path.basename(os.path.dirname(files[0])) == "cat a"      # `_` -> ' ' in the class directory (:1232)

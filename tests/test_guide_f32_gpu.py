@@ -90,18 +90,23 @@ def _engine(cfg, w, B):
     return eng
 
 
-@pytest.mark.parametrize("which", ["tiny", "resnet50"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_grouped", "resnet50", "resnext50", "wideresnet50"])
 def test_guide_forward_and_vjp_vs_oracle(hip_lib, which):
-    """encode_image and its input-gradient, through the production C ABI, at the tiny widths and at the real ResNet-50 widths
-    (64-256-512-1024-2048 at 224x224)."""
-    from distdiff_amd.config import sd15_config, tiny_config
+    """encode_image and its input-gradient, through the production C ABI, at the tiny widths and at the real widths of the three
+    Bottleneck guides of the reference at 224x224: resnet50 (64-256-512-1024-2048), resnext50 = resnext50_32x4d
+    (32 groups in every 3x3) and wideresnet50 = wide_resnet50_2 (model_utils.py:47-79)."""
+    from distdiff_amd.config import GuideConfig, guide_config, sd15_config, tiny_config
     from distdiff_amd.weights import synthetic_weights
     from oracle import sd_oracle as O
     B = 2
     if which == "tiny":
         cfg = tiny_config(max_batch=B)
+    elif which == "tiny_grouped":
+        cfg = tiny_config(max_batch=B)
+        cfg.guide = GuideConfig(stem_channels=16, planes=(16, 32, 32, 64), blocks=(1, 2, 1, 1), input_size=56, cardinality=4, base_width=16)
     else:
         cfg = sd15_config(latent_size=8, max_batch=B)     # SD widths at an 8x8 latent keep the UNet/VAE slabs small; the guide is full size
+        cfg.guide = guide_config(which)
     w = synthetic_weights(cfg, seed=0, num_classes=5)
     eng = _engine(cfg, w, B)
     guide = O.GuideOracle(cfg, w["guide"])
