@@ -95,7 +95,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 // forward.  grid (ceil(Nq / QB), H, B), 256 threads. DSPLIT=1: each wave owns QT 16-query tiles;
 // DSPLIT=4: the 4 waves share one set of QT tiles and each accumulates a quarter of the head dim (d=512).
 // ------------------------------------------------------------------------------------------------
-template <int D, int QT, int KT, int DSPLIT>
+template <int D, int QT, int KT, int DSPLIT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   int klim[QT];   // first masked key of this lane's query row
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    klim[qt] = p.causal ? min(p.Nk, qrow[qt] + 1) : p.Nk;
+    klim[qt] = CAUSAL ? min(p.Nk, qrow[qt] + 1) : p.Nk;
     mrun[qt] = -INFINITY; lsum[qt] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DTW; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       }
     }
     // wave-uniform: only the last tile of a ragged key count (or a causal mask, CLIP text encoder) needs masking
-    const bool partial = k0 + KT > p.Nk || p.causal;
+    const bool partial = k0 + KT > p.Nk || CAUSAL;
     bf16x8 pf[QT][NC];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -555,15 +555,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-template <int D, int QT, int KT, int DSPLIT>
-hipError_t run_fwd(const AttnParams& p, hipStream_t s) {
+template <int D, int QT, int KT, int DSPLIT, bool CAUSAL>
+hipError_t run_fwd2(const AttnParams& p, hipStream_t s) {
   constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
   constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
   constexpr size_t lds = 2 * KT * S;
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<D, QT, KT, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<D, QT, KT, DSPLIT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT, CAUSAL>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
+}
+// the causal mask (CLIP text encoder, forward only) is a template flag: the UNet / VAE loops carry no per-score mask code
+template <int D, int QT, int KT, int DSPLIT>
+hipError_t run_fwd(const AttnParams& p, hipStream_t s) {
+  return p.causal ? run_fwd2<D, QT, KT, DSPLIT, true>(p, s) : run_fwd2<D, QT, KT, DSPLIT, false>(p, s);
 }
 template <int D, int QT, int KT, int DSPLIT>
 hipError_t run_dq(const AttnParams& p, hipStream_t s) {
@@ -596,7 +601,13 @@ hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
   if (!attn_check(p)) return hipErrorInvalidValue;
   switch (p.D) {
     case 32: return run_fwd<32, 2, 64, 1>(p, s);
-    case 40: return run_fwd<40, 2, 64, 1>(p, s);
+#ifndef DD_A40_QT
+#define DD_A40_QT 2
+#endif
+#ifndef DD_A40_KT
+#define DD_A40_KT 64
+#endif
+    case 40: return run_fwd<40, DD_A40_QT, DD_A40_KT, 1>(p, s);
     case 64: return run_fwd<64, 2, 64, 1>(p, s);
     case 80: return run_fwd<80, 2, 64, 1>(p, s);
     case 160: return run_fwd<160, 2, 64, 1>(p, s);

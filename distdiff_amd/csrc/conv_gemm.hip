@@ -307,11 +307,8 @@ int conv_gemm_pick_split(int M, int N, int K) {
   return s;
 }
 
-hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
-  if (p.K & 63) return hipErrorInvalidValue;
-  // the kernels index the input with 32-bit element offsets (outputs and residuals use 64-bit offsets)
-  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0xFFFF0000ull) return hipErrorInvalidValue;
-  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+// kernel / split-K selection shared by the launcher and conv_gemm_can_emit_stats
+static void select_config(const ConvGemmParams& p, size_t partial_cap_bytes, int* cfg_out, int* split_out) {
   const int ksteps = p.K / 64;
   int cfg = ((p.force_small & 1) ? 0 : conv_gemm_big_config(p.M, p.N, p.K, p.flags));
   if (cfg && p.ksplit <= 0) {
@@ -325,8 +322,29 @@ hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStrea
   int split = p.ksplit > 0 ? p.ksplit : (cfg ? big_split(cfg, p.M, p.N, p.K) : small_split(p.M, p.N, p.K));
   while (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > partial_cap_bytes) --split;
   if (!p.partial) split = 1;
-  p.ksplit = nonempty_split(split, ksteps);
-  split = p.ksplit;
+  *cfg_out = cfg;
+  *split_out = nonempty_split(split, ksteps);
+}
+
+bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes) {
+  if ((p.K & 63) || p.M <= 0 || p.N <= 0 || (p.M & 63) || (p.N & 7) || (p.y_ld & 7)) return false;
+  if (p.flags & (CF_GEGLU | CF_OUT_F32 | CF_MASK | CF_RES_F32)) return false;
+  if ((p.flags & CF_RES) && (p.res_ld & 7)) return false;
+  int cfg, split;
+  select_config(p, partial_cap_bytes, &cfg, &split);
+  if (!cfg || split != 1) return false;
+  return true;
+}
+
+hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
+  if (p.K & 63) return hipErrorInvalidValue;
+  // the kernels index the input with 32-bit element offsets (outputs and residuals use 64-bit offsets)
+  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0xFFFF0000ull) return hipErrorInvalidValue;
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if ((p.flags & CF_STATS) && (!p.stats || !conv_gemm_can_emit_stats(p, partial_cap_bytes))) return hipErrorInvalidValue;
+  int cfg, split;
+  select_config(p, partial_cap_bytes, &cfg, &split);
+  p.ksplit = split;
   if (cfg) {
     hipError_t e = launch_conv_gemm_big(p, cfg, stream);
     if (e != hipSuccess) return e;

@@ -33,6 +33,19 @@ __device__ __forceinline__ void dma16(const void* base, void* lds, unsigned voff
 #endif
 }
 
+// sum over the 16 lanes of a DPP row (the 16 pixel rows of an MFMA tile); every lane of the row receives the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  return v;
+}
+
 // FM: 1 = fast staging path only (Cin % 64 == 0, no fused upsample / dilation, <= 32 taps: buffer loads with scalar tap offsets),
 //     0 = general path only (per-lane address arithmetic, global_load_lds).  FE: batched epilogue compiled in.
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
@@ -281,6 +294,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   };
   const float* bias = p.bias;
   if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  // CF_STATS: per-(64-row block, channel) partial statistics of the values this wave stores, for the GroupNorm that consumes the
+  // tensor: s1 / s2 hold this lane's sums over its 4 pixel rows, the 16 lanes of an MFMA row are summed with 4 DPP adds per value,
+  // lane fr == 0 stores (mean, M2) of its 4 channels.  ~8 * TN * 4 VALU per wave and work item.
+  auto emit_stats = [&](float (&s1)[TN][4], float (&s2)[TN][4], int m0w, int nW) {
+    if (m0w >= p.M) return;
+    float* dst0 = p.stats + ((size_t)(m0w >> 6) * p.stats_ld) * 2;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[jn][r]), q = row16_sum(s2[jn][r]);
+        const float mean = a * (1.f / 64.f);
+        o[2 * r] = mean; o[2 * r + 1] = fmaxf(q - a * mean, 0.f);
+      }
+      const int nb = nW + col_of(jn);
+      if (fr == 0 && nb + 4 <= p.N) {
+        float* dst = dst0 + (size_t)nb * 2;
+        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  };
   auto epilogue = [&](int w) {
     const int kz = w % p.ksplit, tile = w / p.ksplit;
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -331,28 +367,41 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
           if constexpr (TN & 1) rvo[i] = *(const uint2*)(rp + co);
         }
       }
+      float s1[TN][4], s2[TN][4];
+      if (fl & CF_STATS) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (m >= p.M) continue;
         bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
-        auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1) {
+        auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1, float* t1, float* t2) {
           float v0 = a[0] * p.alpha + b.x, v1 = a[1] * p.alpha + b.y, v2 = a[2] * p.alpha + b.z, v3 = a[3] * p.alpha + b.w;
           if (fl & CF_RES) {
             v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
             v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
           }
           if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          if (fl & CF_STATS) {
+            t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
+            t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
+            t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
+          }
           return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
         };
 #pragma unroll
         for (int t = 0; t < TN / 2; ++t) {
-          const uint2 lo = four(acc[2 * t][i], bv[2 * t], rvp[i][t].x, rvp[i][t].y);
-          const uint2 hi = four(acc[2 * t + 1][i], bv[2 * t + 1], rvp[i][t].z, rvp[i][t].w);
+          const uint2 lo = four(acc[2 * t][i], bv[2 * t], rvp[i][t].x, rvp[i][t].y, s1[2 * t], s2[2 * t]);
+          const uint2 hi = four(acc[2 * t + 1][i], bv[2 * t + 1], rvp[i][t].z, rvp[i][t].w, s1[2 * t + 1], s2[2 * t + 1]);
           *(uint4*)(yp + cp + 32 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y);
+        if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y, s1[TN - 1], s2[TN - 1]);
       }
+      if (fl & CF_STATS) emit_stats(s1, s2, m0 + wm * (TM * 16), wb);
       return;
     }
     if constexpr ((TN & 1) == 0) {
@@ -389,6 +438,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       }
     }
     }  // FE
+    float s1[TN][4], s2[TN][4];
+    if (p.flags & CF_STATS) {
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * (TM * 16) + i * 16 + fr;
@@ -413,10 +469,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
           float h[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = acc[jn][i][r];
-          Epi::apply(p, bias, m, nb, h, h, 0);
+          Epi::apply(p, bias, m, nb, h, h, 0);     // leaves the stored values (before the bf16 rounding) in h
+          if (p.flags & CF_STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[jn][r] += h[r]; s2[jn][r] = __builtin_fmaf(h[r], h[r], s2[jn][r]); }
+          }
         }
       }
     }
+    if (p.flags & CF_STATS) emit_stats(s1, s2, m0 + wm * (TM * 16), n0 + wn * (TN * 16));
   };
 
   // ---- pipeline: NS = 3 LDS stages, software-pipelined through registers.  K-step s reads its two 32-wide halves as

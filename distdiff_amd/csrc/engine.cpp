@@ -92,8 +92,14 @@ struct Op {
   int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
   int causal = 0, act_kind = 0;
   size_t stats_off = 0;  // fp32 stats / lse in the activation slab
+  bool fused = false;    // OP_CONCAT: both operands live inside the output buffer (column views): no copy, forward or backward
   // backward plan
   bool x_acc = false, res_acc = false, x2_acc = false;
+  bool res_alias = false;   // the residual's gradient buffer IS this op's output-gradient buffer (first write: no copy kernel)
+  // GroupNorm statistics from the producing convolutions (plan_gn_stats): conv ops emit per-(64-row block, channel) partials into
+  // the fp32 block at part_off (CF_STATS), the GroupNorm op merges them instead of reading the tensor once more
+  bool part = false; size_t part_off = 0; int part_ld = 0;
+  std::vector<int> producers;
   double flops = 0;
 };
 
@@ -104,6 +110,7 @@ struct Program {
   size_t scratch_partial = 0, scratch_tmp = 0;  // shared scratch requirements (bytes)
   bool want_grad = false;
   bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
+  mutable std::vector<char> emitted;   // per op, per forward run: this convolution did emit its GroupNorm partials
 
   int tensor(int B, int H, int W, int C, bool grad = true, bool f32_act = false) {
     Tn n;
@@ -456,10 +463,30 @@ struct Builder {
     P.ops.push_back(op);
     return y;
   }
+  // torch.cat([a, b], dim=1) of the UNet's skip connections.  No copy: the output buffer is allocated here and BOTH operands are re-homed
+  // into it as column views (row stride = Ca + Cb), so their producers -- convolutions running long before, on the down path, for the
+  // skip -- write straight into it and every other consumer reads the view through its row stride; the same holds for the gradients
+  // (the split of the backward pass disappears too).  Possible because every kernel takes row strides for inputs and outputs.
   int concat(int a, int b) {
-    const Tn& ta = P.t[a]; const Tn& tb = P.t[b];
-    int y = P.tensor(ta.B, ta.H, ta.W, ta.C + tb.C);
+    const int y = P.tensor(P.t[a].B, P.t[a].H, P.t[a].W, P.t[a].C + P.t[b].C);
     Op op; op.kind = OP_CONCAT; op.x = a; op.x2 = b; op.y = y;
+    auto movable = [&](int id) {
+      const Tn& t = P.t[id];
+      if (t.parent != id || t.f32 || P.f32 || (t.C & 7)) return false;
+      for (size_t k = 0; k < P.t.size(); ++k)
+        if ((int)k != id && P.t[k].parent == id) return false;     // it has views of its own (their offsets would go stale)
+      return true;
+    };
+    if (a != b && movable(a) && movable(b) && !getenv("DD_NO_CONCAT_FUSION")) {
+      const Tn ty = P.t[y];
+      int c0 = 0;
+      for (int id : {a, b}) {
+        Tn& t = P.t[id];
+        t.off = ty.off + (size_t)c0 * 2; t.goff = ty.goff + (size_t)c0 * 2; t.ld = ty.ld; t.parent = y;
+        c0 += t.C;
+      }
+      op.fused = true;
+    }
     P.ops.push_back(op);
     return y;
   }
@@ -502,7 +529,20 @@ void plan_backward(Program& P) {
     Op& op = P.ops[i];
     switch (op.kind) {
       case OP_CONV:
-        if (op.res >= 0) op.res_acc = mark(op.res);
+        if (op.res >= 0) {
+          op.res_acc = mark(op.res);
+          // y = conv(x) + res: g(res) (+)= g(y).  When that is the FIRST contribution to g(res) and both are plain tensors of the same
+          // shape, g(res) simply takes over g(y)'s buffer (g(y) is dead once this op's backward has run; later contributions
+          // accumulate into it) instead of being copied.
+          Tn& r = P.t[op.res]; const Tn& y = P.t[op.y];
+          if (!op.res_acc && r.grad && r.parent == op.res && y.parent == op.y && r.ld == y.ld && r.C == y.C && r.rows == y.rows &&
+              !getenv("DD_NO_GRAD_ALIAS")) {
+            bool has_views = false;
+            for (size_t k = 0; k < P.t.size(); ++k)
+              if ((int)k != op.res && P.t[k].parent == op.res) has_views = true;
+            if (!has_views) { r.goff = y.goff; op.res_alias = true; }
+          }
+        }
         op.x_acc = mark(op.x);
         break;
       case OP_GN: case OP_LN: case OP_MAXPOOL: case OP_GAP:
@@ -514,9 +554,52 @@ void plan_backward(Program& P) {
         if (op.cross_slot < 0) { mark(op.k); mark(op.v); }
         break;
       case OP_CONCAT:
+        if (op.fused) break;       // the operands' gradients are column views of the output's gradient: nothing to move
         op.x_acc = mark(op.x);
         op.x2_acc = mark(op.x2);
         break;
+    }
+  }
+}
+
+// GroupNorm statistics without a pass over the tensor: when every producer of a GroupNorm's input (possibly several convolutions
+// writing column ranges of one concat buffer) is an implicit-GEMM convolution, those convolutions emit per-(64-row block, channel)
+// partial (mean, M2) from their epilogue registers and the GroupNorm merges them.  Whether a convolution can do that depends on the
+// kernel the launcher picks for its shape (conv_gemm_can_emit_stats), so the final decision is taken per run; this pass only sets up
+// the buffers and the producer lists.
+void plan_gn_stats(Program& P) {
+  P.emitted.assign(P.ops.size(), 0);
+  if (P.f32 || getenv("DD_NO_GN_FUSION")) return;
+  std::unordered_map<int, size_t> root_part;
+  for (size_t gi = 0; gi < P.ops.size(); ++gi) {
+    if (P.ops[gi].kind != OP_GN) continue;
+    const Tn x = P.t[P.ops[gi].x];
+    const int root = x.parent;
+    const Tn rt = P.t[root];
+    if (x.f32 || rt.f32 || (x.rows & 63) || ((x.H * x.W) & 63)) continue;
+    const int coff = (int)((x.off - rt.off) / 2);
+    std::vector<int> prod;
+    int covered = 0;
+    bool ok = true;
+    for (size_t oi = 0; oi < gi && ok; ++oi) {
+      const Op& o = P.ops[oi];
+      if (o.y < 0 || (o.kind == OP_CONCAT && o.fused)) continue;
+      const Tn& ty = P.t[o.y];
+      if (ty.parent != root) continue;
+      const int yc = (int)((ty.off - rt.off) / 2);
+      if (yc + ty.C <= coff || yc >= coff + x.C) continue;
+      if (o.kind != OP_CONV || o.cw->geglu || o.cw->f32 || o.out_f32 || yc < coff || yc + ty.C > coff + x.C) { ok = false; break; }
+      prod.push_back((int)oi);
+      covered += ty.C;
+    }
+    if (!ok || covered != x.C) continue;
+    if (!root_part.count(root)) root_part[root] = P.fp32_block((size_t)(rt.rows / 64) * rt.C * 2);
+    Op& g = P.ops[gi];
+    g.part = true; g.part_off = root_part[root] + (size_t)coff * 8; g.part_ld = rt.C; g.producers = prod;
+    for (int oi : prod) {
+      Op& o = P.ops[oi];
+      const int yc = (int)((P.t[o.y].off - rt.off) / 2);
+      o.part = true; o.part_off = root_part[root] + (size_t)yc * 8; o.part_ld = rt.C;
     }
   }
 }
@@ -562,7 +645,7 @@ void run_conv_f32_bwd(const Program& P, const Op& op, const Ctx& c) {
   if (op.res >= 0 && P.t[op.res].grad) {
     const Tn& r = P.t[op.res];
     if (op.res_acc) HIPCHK(launch_add_f32(grad_f32(c, r), r.ld, gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
-    else HIPCHK(launch_copy_f32(gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
+    else if (!op.res_alias) HIPCHK(launch_copy_f32(gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
   }
   if (!x.grad) return;
   ConvF32Params p; memset(&p, 0, sizeof p);
@@ -608,12 +691,30 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
           if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
         }
         p.flags = flags;
+        if (op.part) {
+          p.stats = (float*)(c.act + op.part_off); p.stats_ld = op.part_ld;
+          const bool emit = conv_gemm_can_emit_stats(p, c.partial_cap);
+          if (emit) p.flags |= CF_STATS; else p.stats = nullptr;
+          P.emitted[i] = emit ? 1 : 0;
+        }
         HIPCHK(launch_conv_gemm(p, c.partial_cap, c.s));
         if (c.flops) *c.flops += op.flops;
       } break;
       case OP_GN: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         GroupNormParams p; memset(&p, 0, sizeof p);
+        const float* chan_part = nullptr;
+        if (op.part) {
+          bool all = true;
+          for (int pi : op.producers) all = all && P.emitted[pi];
+          if (all) chan_part = (const float*)(c.act + op.part_off);
+        }
+        if (getenv("DD_GN_REPORT")) {
+          static int n_total = 0, n_fused = 0;
+          ++n_total; n_fused += chan_part ? 1 : 0;
+          if (n_total % 200 == 0) fprintf(stderr, "[gn] %d of %d GroupNorm forwards took their statistics from the producing convolutions\n", n_fused, n_total);
+        }
+        p.chan_part = chan_part; p.part_ld = op.part_ld;
         p.x = act_ptr(c, x); p.x_ld = x.ld; p.y = act_ptr(c, y); p.y_ld = y.ld;
         p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off); p.scratch = c.gn_scratch;
         p.B = x.B; p.HW = x.H * x.W; p.C = x.C; p.G = op.G; p.eps = op.eps; p.silu = op.silu;
@@ -646,6 +747,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         if (c.flops) *c.flops += op.flops;
       } break;
       case OP_CONCAT: {
+        if (op.fused) break;
         const Tn& a = P.t[op.x]; const Tn& b = P.t[op.x2]; const Tn& y = P.t[op.y];
         HIPCHK(launch_copy_bf16(act_ptr(c, a), a.ld, act_ptr(c, y), y.ld, y.rows, a.C, c.s));
         HIPCHK(launch_copy_bf16(act_ptr(c, b), b.ld, act_ptr(c, y) + a.C, y.ld, y.rows, b.C, c.s));
@@ -687,7 +789,7 @@ void run_bwd(const Program& P, const Ctx& c) {
         if (op.res >= 0 && P.t[op.res].grad) {
           const Tn& r = P.t[op.res];
           if (op.res_acc) HIPCHK(launch_add_bf16(grad_ptr(c, r), r.ld, gy, y.ld, grad_ptr(c, r), r.ld, r.rows, r.C, c.s));
-          else HIPCHK(launch_copy_bf16(gy, y.ld, grad_ptr(c, r), r.ld, r.rows, r.C, c.s));
+          else if (!op.res_alias) HIPCHK(launch_copy_bf16(gy, y.ld, grad_ptr(c, r), r.ld, r.rows, r.C, c.s));
         }
         if (!x.grad) break;
         const bf16_t* gin = gy; int gin_ld = y.ld;
@@ -761,6 +863,7 @@ void run_bwd(const Program& P, const Ctx& c) {
         if (c.flops) *c.flops += op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5);
       } break;
       case OP_CONCAT: {
+        if (op.fused) break;
         const Tn& a = P.t[op.x]; const Tn& b = P.t[op.x2]; const Tn& y = P.t[op.y];
         bf16_t* gy = grad_ptr(c, y);
         if (a.grad) {
@@ -883,6 +986,7 @@ void build_unet(dd_engine* E) {
   h = b.gn(h, make_norm(E, m, "conv_norm_out"), G, eps, 1);
   E->unet_out = b.conv(h, make_conv(E, m, "conv_out", 1), 1, 0, -1, 0, 1);
   if (P.want_grad) plan_backward(P);
+  plan_gn_stats(P);
 }
 
 void build_vae(dd_engine* E) {
@@ -922,6 +1026,7 @@ void build_vae(dd_engine* E) {
   // the image leaves the decoder in fp32 (no bf16 rounding in front of the guide's ReLU masks or the uint8 quantisation)
   E->vae_out = b.conv(h, make_conv(E, m, "decoder.conv_out", 1), 1, 0, -1, 0, /*out_f32=*/1);
   if (P.want_grad) plan_backward(P);
+  plan_gn_stats(P);
 }
 
 // f-2: AutoencoderKL.encode (dataloader.py:808) -- Encoder: conv_in, DownEncoderBlock2D x levels (resnets +
@@ -964,6 +1069,7 @@ void build_vae_encoder(dd_engine* E) {
   h = b.gn(h, make_norm(E, m, "encoder.conv_norm_out"), G, eps, 1);
   h = b.conv(h, make_conv(E, m, "encoder.conv_out", 1));
   E->venc_out = b.conv(h, make_conv(E, m, "quant_conv", 0), 1, 0, -1, 0, /*out_f32=*/1);
+  plan_gn_stats(P);
 }
 
 // f-2: CLIPTextModel (transformers; dataloader.py:633-646 `text_encoder(input_ids)[0]`): token + position embeddings, pre-LN
@@ -1036,6 +1142,7 @@ void build_guide(dd_engine* E) {
     }
   E->guide_feat = h;
   if (P.want_grad) plan_backward(P);
+  plan_gn_stats(P);
 }
 
 // ---------------------------------------------------------------------------------------------------

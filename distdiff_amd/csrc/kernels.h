@@ -21,7 +21,9 @@ enum ConvFlags {
   CF_OUT_F32 = 16,   // store fp32 instead of bf16
   CF_MASK = 32,      // multiply by (mask[m, n] > 0)   (ReLU backward)
   CF_RES_F32 = 64,   // residual is fp32
-  CF_GEGLU_RAW = 128 // with CF_GEGLU: also store the raw packed pre-activation (bf16) to raw[m, N]
+  CF_GEGLU_RAW = 128,// with CF_GEGLU: also store the raw packed pre-activation (bf16) to raw[m, N]
+  CF_STATS = 256     // also emit per-(64-row block, output channel) partial statistics (mean, M2) of the stored values: the
+                     // GroupNorm that consumes this tensor then needs no statistics pass of its own (conv_gemm_can_emit_stats)
 };
 
 struct ConvGemmParams {
@@ -35,7 +37,8 @@ struct ConvGemmParams {
   const bf16_t* mask;   // relu mask source or null
   bf16_t* raw;          // GEGLU raw output or null
   float* partial;       // split-K workspace [ksplit][M][N] fp32 (ksplit > 1)
-  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride;
+  float* stats;         // CF_STATS: [M / 64][stats_ld][2] fp32 (mean, M2 of 64 rows), already offset to this op's first channel
+  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride, stats_ld;
   int B, H, W;          // stored input geometry
   int Ho, Wo;           // output geometry
   int stride;           // output->logical-input stride (1 or 2)
@@ -53,6 +56,9 @@ struct ConvGemmParams {
 hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream);
 // Preferred split for a shape (used by the engine to size the workspace).
 int conv_gemm_pick_split(int M, int N, int K);
+// true iff launch_conv_gemm(p, partial_cap_bytes) will honour CF_STATS for this problem (persistent big-tile kernel, no split-K,
+// M % 64 == 0, plain bf16 output): the caller asks before setting the flag and falls back to the GroupNorm statistics pass otherwise
+bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes);
 
 // ----------------------------------------------------------------------------------------------
 // K3: GroupNorm (+ optional SiLU) forward / backward on NHWC bf16.
@@ -63,6 +69,8 @@ struct GroupNormParams {
   const float* gamma; const float* beta;   // [C]
   float* stats;        // [B][G][2] (mean, rstd), written by fwd, read by bwd
   float* scratch;      // [B][S][G][3] partial (count, mean, M2) / bwd partial sums
+  const float* chan_part;  // fwd, optional: per-(64-row block, channel) partials (mean, M2) emitted by the producing convolutions
+  int part_ld;             //   (CF_STATS), [B*HW/64][part_ld][2], already offset to channel 0 of x: replaces the statistics pass
   int B, HW, C, G;
   float eps;
   int silu;

@@ -159,6 +159,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(GroupNormParams
   }
 }
 
+// Pass 1+2 when the producing convolutions emitted per-(64-row block, channel) partials (mean, M2 over 64 rows; CF_STATS of the
+// implicit-GEMM epilogue): one wave per (b, g) merges the (HW / 64) x (C / G) partials of its group, no pass over the tensor.
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_chan_kernel(GroupNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int bg = blockIdx.x * (GN_THREADS / 64) + (threadIdx.x >> 6);
+  if (bg >= p.B * p.G) return;
+  const int b = bg / p.G, g = bg % p.G;
+  const int cpg = p.C / p.G, nb = p.HW >> 6, P = nb * cpg;
+  float n = 0.f, mean = 0.f, M2 = 0.f;
+  for (int e = lane; e < P; e += 64) {
+    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+    const float2 in = *(const float2*)(p.chan_part + (((size_t)b * nb + rb) * p.part_ld + c) * 2);
+    const float nn = n + 64.f, d = in.x - mean;
+    mean += d * (64.f / nn);
+    M2 += in.y + d * d * (n * 64.f / nn);
+    n = nn;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float nb2 = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), M2b = __shfl_xor(M2, o, 64);
+    const float nn = n + nb2;
+    if (nn > 0.f) {
+      const float lo_n = (lane & o) ? nb2 : n, hi_n = (lane & o) ? n : nb2;
+      const float lo_m = (lane & o) ? mb : mean, hi_m = (lane & o) ? mean : mb;
+      const float lo_M = (lane & o) ? M2b : M2, hi_M = (lane & o) ? M2 : M2b;
+      const float d = hi_m - lo_m;
+      mean = lo_m + d * (hi_n / nn);
+      M2 = lo_M + hi_M + d * d * (lo_n * hi_n / nn);
+      n = nn;
+    }
+  }
+  if (lane == 0) {
+    p.stats[((size_t)b * p.G + g) * 2] = mean;
+    p.stats[((size_t)b * p.G + g) * 2 + 1] = rsqrtf(fmaxf(M2, 0.f) / n + p.eps);
+  }
+}
+
 // Pass 3: build the per-channel affine in LDS, stream the tensor (4 vectors in flight per thread).
 template <bool BWD>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p, const float* fin) {
@@ -359,8 +396,13 @@ template <bool BWD>
 static hipError_t gn_launch(const GroupNormParams& p, hipStream_t stream) {
   const int S = gn_split(p.HW, p.C);
   float* fin = p.scratch + (size_t)p.B * GN_MAX_SPLIT * p.G * 3;   // [B][G][2] finalize output of the backward sums
-  hipLaunchKernelGGL((gn_partial_kernel<BWD>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
-  hipLaunchKernelGGL((gn_finalize_kernel<BWD>), dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p, S, fin);
+  if (!BWD && p.chan_part) {
+    if (p.HW & 63) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_chan_kernel, dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((gn_partial_kernel<BWD>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
+    hipLaunchKernelGGL((gn_finalize_kernel<BWD>), dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p, S, fin);
+  }
   hipLaunchKernelGGL((gn_apply_kernel<BWD>), dim3(gn_apply_blocks(p), p.B), dim3(GN_THREADS), (BWD ? 6 : 2) * p.C * sizeof(float), stream, p,
                      (const float*)fin);
   return hipGetLastError();

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, AttnParams,
+from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, CF_STATS, AttnParams,
                    ConvGemmParams, GroupNormParams, LayerNormParams, check)
 
 
@@ -101,8 +101,10 @@ def conv_f32(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask
 
 
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
-              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False):
-    """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)]."""
+              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False, stats=None):
+    """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)].  stats: fp32 [M/64, C, 2] buffer (or a column view of one) to
+    receive the per-(64-row block, channel) partial (mean, M2) of the stored values (CF_STATS; the launch fails if the kernel the
+    launcher picks for this shape cannot emit them)."""
     p = ConvGemmParams()
     M = B * Ho * Wo
     ncols = pk.N // 2 if pk.geglu else pk.N
@@ -140,13 +142,16 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
         cap = partial.numel() * 4
     p.B, p.H, p.W, p.Ho, p.Wo, p.stride, p.shift, p.parity = B, H, W, Ho, Wo, stride, shift, parity
     p.cin, p.ntaps, p.M, p.N, p.K = pk.cin, pk.ntaps, M, pk.N, pk.K
+    if stats is not None:
+        flags |= CF_STATS
+        p.stats, p.stats_ld = _ptr(stats), stats.stride(0) // 2
     p.ksplit, p.flags, p.alpha = ksplit, flags, alpha
     p.force_small = int(force_small)
     check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
     return y
 
 
-def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None):
+def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None, chan_part=None):
     Cc = x.shape[1]
     L = _lib.lib()
     p = GroupNormParams()
@@ -157,6 +162,8 @@ def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None):
     p.x, p.x_ld, p.y, p.y_ld = _ptr(x), x.stride(0), _ptr(y), y.stride(0)
     p.gamma, p.beta, p.stats, p.scratch = _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(scratch)
     p.B, p.HW, p.C, p.G, p.eps, p.silu = B, HW, Cc, G, eps, int(silu)
+    if chan_part is not None:     # [B*HW/64, C_total, 2] partials emitted by the producing convolutions (a column view is fine)
+        p.chan_part, p.part_ld = _ptr(chan_part), chan_part.stride(0) // 2
     if dy is None:
         check(L.dd_op_groupnorm_fwd(C.byref(p), _stream()), "gn_fwd")
         return y, stats

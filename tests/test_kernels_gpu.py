@@ -392,3 +392,52 @@ def test_bicubic_maxpool_gap_energy(ops):
         torch.cuda.synchronize()
         assert_close(score, sc.detach().reshape(1), rtol=1e-5, atol=1e-6, what="energy score n=%d" % normalize)
         assert_close(gf, gf_ref, rtol=1e-4, atol=1e-7, what="energy grad n=%d" % normalize)
+
+
+STATS_CASES = [
+    # name, B, Cin, Cout, H, W, k, res (exercise: 256x160 FE epilogue, 128x160 two-workgroup form, deep-K generic epilogue, 256x128)
+    # (shapes large enough for the persistent kernel without split-K: >= 192 work items)
+    ("fe_128x160_3x3", 2, 64, 320, 96, 96, 3, True),
+    ("fe_1x1_res", 2, 320, 640, 64, 64, 1, True),
+    ("generic_256x160_deepK", 2, 960, 320, 128, 128, 3, False),
+    ("two_wg_128x128", 1, 128, 128, 256, 256, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_conv_emits_groupnorm_partials(ops, case):
+    """CF_STATS: the implicit-GEMM epilogue also emits per-(64-row block, channel) partial (mean, M2) of the values it stores, and
+    GroupNorm(+SiLU) computed from those partials (no statistics pass over the tensor) matches torch on the conv output."""
+    name, B, Cin, Cout, H, W, k, with_res = case
+    g = torch.Generator().manual_seed(len(name))
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    bias = torch.randn(Cout, generator=g)
+    res = bf(torch.randn(B, Cout, H, W, generator=g)) if with_res else None
+    ref = F.conv2d(x, w, bias, padding=k // 2) + (res if with_res else 0)
+    M = B * H * W
+    xd = ops.to_nhwc_bf16(x, Cin).cuda()
+    pk = ops.PackedConv(w, k // 2, mode=0, bias=bias)
+    # the tensor sits in columns [64, 64 + Cout) of a wider "concat" buffer: strided output, strided partials
+    Ct = Cout + 64
+    ybuf = torch.zeros(M, Ct, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros(M // 64, Ct, 2, device="cuda", dtype=torch.float32)
+    resd = ops.to_nhwc_bf16(res, Cout).cuda() if with_res else None
+    y = ops.conv_gemm(xd, pk, B, H, W, H, W, res=resd, y=ybuf[:, 64:], stats=part[:, 64:])
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(ybuf[:, 64:], B, H, W), ref, what=name + " conv")
+    rows = ref.permute(0, 2, 3, 1).reshape(M // 64, 64, Cout)              # the fp32 values before the bf16 rounding of the store
+    pm, pM2 = part[:, 64:, 0].cpu(), part[:, 64:, 1].cpu()
+    assert_close(pm, rows.mean(1), rtol=2e-3, atol=2e-3, what=name + " partial mean")
+    assert_close(pM2, ((rows - rows.mean(1, keepdim=True)) ** 2).sum(1), rtol=2e-2, atol=2e-2, what=name + " partial M2")
+    assert float(part[:, :64].abs().max()) == 0.0                          # nothing outside the op's channel range
+    # GroupNorm from the partials
+    G, eps = 32, 1e-5
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    yv = ybuf[:, 64:]
+    got, stats = ops.groupnorm(yv, gamma.cuda(), beta.cuda(), B, H * W, G, eps, True, chan_part=part[:, 64:])
+    xq = ops.from_nhwc(yv, B, H, W).cpu()
+    want = F.silu(F.group_norm(xq, G, gamma, beta, eps))
+    assert_close(ops.from_nhwc(got, B, H, W), want, what=name + " gn from partials")
+    plain, stats2 = ops.groupnorm(yv, gamma.cuda(), beta.cuda(), B, H * W, G, eps, True)
+    assert_close(stats, stats2, rtol=2e-3, atol=2e-3, what=name + " stats vs statistics pass")
