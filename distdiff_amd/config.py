@@ -67,21 +67,32 @@ class GuideConfig:
     base_width: int = 64               # resnet50 (1, 64), resnext50_32x4d (32, 4), wide_resnet50_2 (1, 128)  (model_utils.py:47-79)
     bn_eps: float = 1e-5
     input_size: int = 224              # F.interpolate(..., (224,224), 'bicubic') generate_data.py:704
+    # kind "vit": the image tower of an open_clip ViT (open_clip_vit_b32 = 'ViT-B-32': width 768, 12 layers, 12 heads, patch 32, MLP
+    # 4x, nn.GELU, projection to 512); encode_image = CLIP.encode_image = visual(x) (model_utils.py:80-87)
+    kind: str = "resnet"
+    vit_width: int = 768
+    vit_layers: int = 12
+    vit_heads: int = 12
+    vit_patch: int = 32
+    vit_mlp: int = 3072
+    vit_out: int = 512
+    vit_act: str = "gelu"
 
     @property
     def feature_dim(self):
-        return self.planes[-1] * self.expansion
+        return self.vit_out if self.kind == "vit" else self.planes[-1] * self.expansion
 
     def width(self, planes):
         return int(planes * self.base_width / 64) * self.cardinality
 
 
-# the reference's guide architectures that are ResNet Bottleneck networks (model_utils.py:47-79); mobilenetv2 and open_clip_vit_b32
-# (:64-70, :80-87) are other network families and are not built
+# the reference's guide architectures (model_utils.py:47-87): the three timm Bottleneck ResNets (exact fp32 program) and the open_clip
+# ViT-B/32 image tower (bf16 program); mobilenetv2 (:64-71) is not built
 GUIDE_ARCHS = {
     "resnet50": dict(cardinality=1, base_width=64),
     "resnext50": dict(cardinality=32, base_width=4),          # timm resnext50_32x4d
     "wideresnet50": dict(cardinality=1, base_width=128),      # timm wide_resnet50_2
+    "open_clip_vit_b32": dict(kind="vit"),                    # open_clip 'ViT-B-32' image tower (the reference's default --arch)
 }
 
 

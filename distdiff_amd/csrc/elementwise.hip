@@ -514,6 +514,76 @@ __global__ void act_bf16_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, in
     y[r * ldy + c] = f2bf(o);
   }
 }
+// y = act'(x) * dy  (kind 0 quick_gelu, 1 erf-GELU): backward of act_bf16_kernel (CLIP ViT guide MLP)
+__global__ void act_bwd_bf16_kernel(const bf16_t* x, int ldx, const bf16_t* dy, int ldd, bf16_t* dx, int ldo, int M, int C, int kind, int acc) {
+  const size_t total = (size_t)M * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const float v = bf2f(x[r * ldx + c]);
+    float d;
+    if (kind == 0) { const float sg = 1.f / (1.f + __expf(-1.702f * v)); d = sg * (1.f + 1.702f * v * (1.f - sg)); }
+    else d = dgelu_f(v);
+    float o = d * bf2f(dy[r * ldd + c]);
+    if (acc) o += bf2f(dx[r * ldo + c]);
+    dx[r * ldo + c] = f2bf(o);
+  }
+}
+// CLIP ViT patch embedding as a GEMM: image fp32 NHWC [B,S,S,ld] -> rows [B*(S/p)^2, C*p*p] bf16 with k = (c, iy, ix), the flattening
+// of conv1.weight [width, C, p, p] (open_clip VisionTransformer.conv1, stride = kernel = p: the patches do not overlap); and its
+// transpose (every pixel belongs to exactly one patch: a pure re-layout, no accumulation)
+__global__ void patchify_kernel(const float* img, int ld, bf16_t* out, int B, int S, int p, int C) {
+  const int g = S / p, K = C * p * p;
+  GRID_STRIDE(i, (size_t)B * g * g * K) {
+    const int k = (int)(i % K);
+    const size_t row = i / K;
+    const int px = (int)(row % g), py = (int)((row / g) % g), b = (int)(row / ((size_t)g * g));
+    const int ix = k % p, iy = (k / p) % p, c = k / (p * p);
+    out[i] = f2bf(img[(((size_t)b * S + py * p + iy) * S + px * p + ix) * ld + c]);
+  }
+}
+__global__ void patchify_bwd_kernel(const bf16_t* gout, float* gimg, int ld, int B, int S, int p, int C) {
+  const int g = S / p, K = C * p * p;
+  GRID_STRIDE(i, (size_t)B * S * S * C) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int x = (int)(pix % S), y = (int)((pix / S) % S), b = (int)(pix / ((size_t)S * S));
+    const size_t row = ((size_t)b * g + y / p) * g + x / p;
+    gimg[pix * ld + c] = bf2f(gout[row * K + (c * p + y % p) * p + x % p]);
+  }
+}
+// x = cat([class_embedding, patches], dim=1) + positional_embedding: rows [B*(np+1), W]; backward drops the class row
+__global__ void vit_embed_kernel(const bf16_t* patches, int ldp, const float* cls, const float* pos, bf16_t* out, int ldo, int B, int np, int W) {
+  GRID_STRIDE(i, (size_t)B * (np + 1) * W) {
+    const int c = (int)(i % W);
+    const size_t row = i / W;
+    const int t = (int)(row % (np + 1)), b = (int)(row / (np + 1));
+    const float v = t == 0 ? cls[c] : bf2f(patches[((size_t)b * np + t - 1) * ldp + c]);
+    out[row * ldo + c] = f2bf(v + pos[(size_t)t * W + c]);
+  }
+}
+__global__ void vit_embed_bwd_kernel(const bf16_t* gout, int ldo, bf16_t* gp, int ldp, int B, int np, int W) {
+  GRID_STRIDE(i, (size_t)B * np * W) {
+    const int c = (int)(i % W);
+    const size_t row = i / W;
+    const int t = (int)(row % np), b = (int)(row / np);
+    gp[row * ldp + c] = gout[((size_t)b * (np + 1) + t + 1) * ldo + c];
+  }
+}
+// y[b, :] = x[b * stride, :] (the class token of every image); backward: dx = 0 except those rows (first write of dx)
+__global__ void select_rows_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, int B, int stride, int C) {
+  GRID_STRIDE(i, (size_t)B * C) { const int c = (int)(i % C); const size_t b = i / C; y[b * ldy + c] = x[b * stride * ldx + c]; }
+}
+__global__ void select_rows_bwd_kernel(const bf16_t* dy, int ldy, bf16_t* dx, int ldx, int B, int stride, int C, int acc) {
+  GRID_STRIDE(i, (size_t)B * stride * C) {
+    const int c = (int)(i % C);
+    const size_t row = i / C;
+    const bool sel = (row % stride) == 0;
+    float v = sel ? bf2f(dy[(row / stride) * ldy + c]) : 0.f;
+    if (acc) v += bf2f(dx[row * ldx + c]);
+    dx[row * ldx + c] = f2bf(v);
+  }
+}
 // DiagonalGaussianDistribution.sample() * scaling_factor (dataloader.py:808-809): moments NHWC fp32 [B*HW, ld] = (mean | logvar),
 // logvar clamped to [-30, 20]; noise NCHW fp32 or null (-> the mode).  latents NCHW fp32; optional moments_out NCHW [B, 2C, HW].
 __global__ void vae_sample_kernel(const float* mom, int ld, const float* noise, float* lat, float* mom_out, int B, int C, int HW,
@@ -644,6 +714,31 @@ hipError_t launch_clip_embed(const int* ids, const float* tok, const float* pos,
 }
 hipError_t launch_act_bf16(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, int kind, hipStream_t s) {
   LAUNCH(act_bf16_kernel, (size_t)M * C, x, ldx, y, ldy, M, C, kind);
+}
+hipError_t launch_act_bwd_bf16(const bf16_t* x, int ldx, const bf16_t* dy, int ldd, bf16_t* dx, int ldo, int M, int C, int kind, int accumulate,
+                               hipStream_t s) {
+  LAUNCH(act_bwd_bf16_kernel, (size_t)M * C, x, ldx, dy, ldd, dx, ldo, M, C, kind, accumulate);
+}
+hipError_t launch_patchify(const float* img, int ld, bf16_t* out, int B, int S, int p, int C, hipStream_t s) {
+  if (S % p) return hipErrorInvalidValue;
+  LAUNCH(patchify_kernel, (size_t)B * S * S * C, img, ld, out, B, S, p, C);
+}
+hipError_t launch_patchify_bwd(const bf16_t* gout, float* gimg, int ld, int B, int S, int p, int C, hipStream_t s) {
+  if (S % p) return hipErrorInvalidValue;
+  LAUNCH(patchify_bwd_kernel, (size_t)B * S * S * C, gout, gimg, ld, B, S, p, C);
+}
+hipError_t launch_vit_embed(const bf16_t* patches, int ldp, const float* cls, const float* pos, bf16_t* out, int ldo, int B, int np, int W,
+                            hipStream_t s) {
+  LAUNCH(vit_embed_kernel, (size_t)B * (np + 1) * W, patches, ldp, cls, pos, out, ldo, B, np, W);
+}
+hipError_t launch_vit_embed_bwd(const bf16_t* gout, int ldo, bf16_t* gp, int ldp, int B, int np, int W, hipStream_t s) {
+  LAUNCH(vit_embed_bwd_kernel, (size_t)B * np * W, gout, ldo, gp, ldp, B, np, W);
+}
+hipError_t launch_select_rows(const bf16_t* x, int ldx, bf16_t* y, int ldy, int B, int stride, int C, hipStream_t s) {
+  LAUNCH(select_rows_kernel, (size_t)B * C, x, ldx, y, ldy, B, stride, C);
+}
+hipError_t launch_select_rows_bwd(const bf16_t* dy, int ldy, bf16_t* dx, int ldx, int B, int stride, int C, int accumulate, hipStream_t s) {
+  LAUNCH(select_rows_bwd_kernel, (size_t)B * stride * C, dy, ldy, dx, ldx, B, stride, C, accumulate);
 }
 hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
                              float scale, hipStream_t s) {

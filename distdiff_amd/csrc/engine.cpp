@@ -78,9 +78,10 @@ struct Tn {              // activation tensor or channel view
   int parent = -1;       // gradient-tracking parent (self for base tensors)
   int rows = 0, C = 0, ld = 0, B = 0, H = 0, W = 0;
   bool f32 = false, grad = false;
+  bool gf32 = false;     // the gradient of this tensor is fp32 (always in fp32 programs; the image input of the ViT guide)
 };
 
-enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT };
+enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT, OP_PATCHIFY, OP_VITEMBED, OP_SELECT };
 
 struct Op {
   OpKind kind;
@@ -91,6 +92,7 @@ struct Op {
   int G = 0, silu = 0; float eps = 0;
   int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
   int causal = 0, act_kind = 0;
+  int patch = 0, sel_stride = 0;   // OP_PATCHIFY: patch size; OP_SELECT: row stride (tokens per image)
   size_t stats_off = 0;  // fp32 stats / lse in the activation slab
   bool fused = false;    // OP_CONCAT: both operands live inside the output buffer (column views): no copy, forward or backward
   // backward plan
@@ -112,13 +114,14 @@ struct Program {
   bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
   mutable std::vector<char> emitted;   // per op, per forward run: this convolution did emit its GroupNorm partials
 
-  int tensor(int B, int H, int W, int C, bool grad = true, bool f32_act = false) {
+  int tensor(int B, int H, int W, int C, bool grad = true, bool f32_act = false, bool f32_grad = false) {
     Tn n;
     n.B = B; n.H = H; n.W = W; n.rows = B * H * W; n.C = C; n.ld = f32 ? rup(C, 4) : rup(C, 8); n.f32 = f32_act || f32;
     n.grad = grad && want_grad;
+    n.gf32 = f32 || f32_grad;
     n.off = act_bytes;
     act_bytes += rup_sz((size_t)n.rows * n.ld * (n.f32 ? 4 : 2), 256);
-    if (n.grad) { n.goff = grad_bytes; grad_bytes += rup_sz((size_t)n.rows * n.ld * (f32 ? 4 : 2), 256); }
+    if (n.grad) { n.goff = grad_bytes; grad_bytes += rup_sz((size_t)n.rows * n.ld * (n.gf32 ? 4 : 2), 256); }
     n.parent = (int)t.size();
     t.push_back(n);
     return (int)t.size() - 1;
@@ -490,10 +493,34 @@ struct Builder {
     P.ops.push_back(op);
     return y;
   }
-  int act(int x, int kind) {   // forward-only programs (text encoder MLP)
+  int act(int x, int kind) {   // text encoder MLP (forward only), ViT guide MLP (with backward)
     const Tn& tx = P.t[x];
     int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
     Op op; op.kind = OP_ACT; op.x = x; op.y = y; op.act_kind = kind;
+    P.ops.push_back(op);
+    return y;
+  }
+  // ViT guide: image [B,S,S,3] fp32 -> patch rows [B*(S/p)^2, 3*p*p]
+  int patchify(int x, int p) {
+    const Tn& tx = P.t[x];
+    const int g = tx.H / p;
+    int y = P.tensor(tx.B, g * g, 1, tx.C * p * p);
+    Op op; op.kind = OP_PATCHIFY; op.x = x; op.y = y; op.patch = p;
+    P.ops.push_back(op);
+    return y;
+  }
+  // class token + positional embedding (nw->gamma = class_embedding [W], nw->beta = positional_embedding [(np+1)*W])
+  int vit_embed(int x, NormW* emb) {
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, tx.H + 1, 1, tx.C);
+    Op op; op.kind = OP_VITEMBED; op.x = x; op.y = y; op.nw = emb;
+    P.ops.push_back(op);
+    return y;
+  }
+  int select_first(int x) {     // the class token of every image
+    const Tn& tx = P.t[x];
+    int y = P.tensor(tx.B, 1, 1, tx.C);
+    Op op; op.kind = OP_SELECT; op.x = x; op.y = y; op.sel_stride = tx.H * tx.W;
     P.ops.push_back(op);
     return y;
   }
@@ -548,7 +575,9 @@ void plan_backward(Program& P) {
       case OP_GN: case OP_LN: case OP_MAXPOOL: case OP_GAP:
         op.x_acc = mark(op.x);
         break;
-      case OP_ACT: throw std::runtime_error("OP_ACT has no backward (forward-only programs)");
+      case OP_ACT: case OP_PATCHIFY: case OP_VITEMBED: case OP_SELECT:
+        op.x_acc = mark(op.x);
+        break;
       case OP_ATTN:
         mark(op.q);
         if (op.cross_slot < 0) { mark(op.k); mark(op.v); }
@@ -761,6 +790,18 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         HIPCHK(launch_act_bf16(act_ptr(c, x), x.ld, act_ptr(c, y), y.ld, x.rows, x.C, op.act_kind, c.s));
       } break;
+      case OP_PATCHIFY: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_patchify(act_f32(c, x), x.ld, act_ptr(c, y), x.B, x.H, op.patch, x.C, c.s));
+      } break;
+      case OP_VITEMBED: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_vit_embed(act_ptr(c, x), x.ld, op.nw->gamma, op.nw->beta, act_ptr(c, y), y.ld, x.B, x.H, x.C, c.s));
+      } break;
+      case OP_SELECT: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_select_rows(act_ptr(c, x), x.ld, act_ptr(c, y), y.ld, x.B, op.sel_stride, x.C, c.s));
+      } break;
       case OP_GAP: break;
     }
     if (c.prof) c.prof->end(c.s);
@@ -882,7 +923,29 @@ void run_bwd(const Program& P, const Ctx& c) {
         if (P.f32) HIPCHK(launch_maxpool3x3s2_bwd_f32(act_f32(c, x), grad_f32(c, y), grad_f32(c, x), x.B, x.H, x.W, x.ld, c.s));
         else HIPCHK(launch_maxpool3x3s2_bwd(act_ptr(c, x), grad_ptr(c, y), grad_ptr(c, x), x.B, x.H, x.W, x.C, c.s));
       } break;
-      case OP_GAP: case OP_ACT: break;
+      case OP_ACT: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        HIPCHK(launch_act_bwd_bf16(act_ptr(c, x), x.ld, grad_ptr(c, y), y.ld, grad_ptr(c, x), x.ld, x.rows, x.C, op.act_kind, op.x_acc ? 1 : 0, c.s));
+      } break;
+      case OP_PATCHIFY: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        if (op.x_acc || !x.gf32) throw std::runtime_error("patchify backward: the image gradient must be an fp32 first write");
+        HIPCHK(launch_patchify_bwd(grad_ptr(c, y), grad_f32(c, x), x.ld, x.B, x.H, op.patch, x.C, c.s));
+      } break;
+      case OP_VITEMBED: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        if (op.x_acc) throw std::runtime_error("vit_embed backward accumulate unsupported");
+        HIPCHK(launch_vit_embed_bwd(grad_ptr(c, y), y.ld, grad_ptr(c, x), x.ld, x.B, x.H, x.C, c.s));
+      } break;
+      case OP_SELECT: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        HIPCHK(launch_select_rows_bwd(grad_ptr(c, y), y.ld, grad_ptr(c, x), x.ld, x.B, op.sel_stride, x.C, op.x_acc ? 1 : 0, c.s));
+      } break;
+      case OP_GAP: break;
     }
   }
 }
@@ -1145,6 +1208,80 @@ void build_guide(dd_engine* E) {
   plan_gn_stats(P);
 }
 
+// open_clip VisionTransformer (the image tower behind `image_encoder.encode_image` when --arch open_clip_vit_b32, the reference's default
+// guide; model_utils.py:80-87): conv1 (stride = kernel = patch, no bias) -> [class_embedding; patches] + positional_embedding -> ln_pre ->
+// residual attention blocks (ln_1 -> nn.MultiheadAttention (fused in_proj) -> +x ; ln_2 -> c_fc -> GELU -> c_proj -> +x) -> ln_post on
+// the class token -> @ proj.  No ReLU / max-pool masks: bf16 MFMA like the UNet.  Width, depth, MLP size and output dim come from the
+// state dict; heads / patch / activation from dd_config.
+void build_guide_vit(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->guide;
+  P.want_grad = c.enable_grad != 0;
+  Builder b(E, P);
+  const std::string m = "guide", v = "visual.";
+  const int B = c.max_batch, S = c.guide_input_size, p = c.guide_vit_patch;
+  if (p < 1 || S % p) throw std::runtime_error("ViT guide: guide_input_size must be a multiple of the patch size");
+  const HostTensor& w1 = E->get(m, v + "conv1.weight");
+  const int W = (int)w1.shape[0];
+  const int heads = c.guide_vit_heads > 0 ? c.guide_vit_heads : W / 64;
+  if ((int)w1.shape[2] != p || (int)w1.shape[3] != p || W % heads) throw std::runtime_error("ViT guide: conv1 / heads do not match the config");
+  const int np = (S / p) * (S / p);
+  E->guide_in = P.tensor(B, S, S, 3, true, /*f32_act=*/true, /*f32_grad=*/true);
+  int h = b.patchify(E->guide_in, p);
+  // conv1 as a linear over the flattened patch: weight [W, 3*p*p], k = (c, iy, ix) = the memory order of conv1.weight
+  h = b.conv(h, make_conv_raw(E, w1.data.data(), nullptr, false, W, 3 * p * p, 1, 1, 0, false, c.enable_grad != 0));
+  {
+    auto nw = std::make_unique<NormW>();
+    const HostTensor& ce = E->get(m, v + "class_embedding");
+    const HostTensor& pe = E->get(m, v + "positional_embedding");
+    if ((int)ce.numel() != W || (int)pe.numel() != (np + 1) * W) throw std::runtime_error("ViT guide: embedding shapes do not match the input size");
+    nw->C = W;
+    nw->gamma = (float*)E->wupload(ce.data.data(), ce.numel() * 4);
+    nw->beta = (float*)E->wupload(pe.data.data(), pe.numel() * 4);
+    E->norms.push_back(std::move(nw));
+    h = b.vit_embed(h, E->norms.back().get());
+  }
+  const float eps = 1e-5f;
+  int x = b.ln(h, make_norm(E, m, v + "ln_pre"), eps);
+  char buf[160];
+  const int N = np + 1;
+  for (int l = 0;; ++l) {
+    snprintf(buf, sizeof buf, "%stransformer.resblocks.%d", v.c_str(), l);
+    const std::string r = buf;
+    if (!E->has(m, r + ".ln_1.weight")) break;
+    int n = b.ln(x, make_norm(E, m, r + ".ln_1"), eps);
+    const HostTensor& iw = E->get(m, r + ".attn.in_proj_weight");
+    const HostTensor& ib = E->get(m, r + ".attn.in_proj_bias");
+    int qkv = b.conv(n, make_conv_raw(E, iw.data.data(), ib.data.data(), true, 3 * W, W, 1, 1, 0, false, c.enable_grad != 0));
+    int q = P.view(qkv, 0, W), k = P.view(qkv, W, W), vv = P.view(qkv, 2 * W, W);
+    int a = b.attn(q, k, vv, heads, N, N, -1);
+    x = b.conv(a, make_conv(E, m, r + ".attn.out_proj", 0), 1, 0, x);
+    n = b.ln(x, make_norm(E, m, r + ".ln_2"), eps);
+    int f = b.conv(n, make_conv(E, m, r + ".mlp.c_fc", 0));
+    f = b.act(f, c.guide_vit_act);
+    x = b.conv(f, make_conv(E, m, r + ".mlp.c_proj", 0), 1, 0, x);
+  }
+  int cls = b.select_first(x);
+  cls = b.ln(cls, make_norm(E, m, v + "ln_post"), eps);
+  // pooled @ proj: proj is [W, D]; as a linear layer its weight is proj^T [D, W]
+  const HostTensor& pr = E->get(m, v + "proj");
+  const int D = (int)pr.shape[1];
+  std::vector<float> pt;
+  if (!E->shape_only) {
+    pt.resize((size_t)D * W);
+    for (int d = 0; d < D; ++d)
+      for (int k = 0; k < W; ++k) pt[(size_t)d * W + k] = pr.data[(size_t)k * D + d];
+  }
+  E->guide_feat = b.conv(cls, make_conv_raw(E, pt.data(), nullptr, false, D, W, 1, 1, 0, false, c.enable_grad != 0), 1, 0, -1, 0, /*out_f32=*/1);
+  if (D != c.guide_feature_dim) throw std::runtime_error("ViT guide: projection dim != guide_feature_dim");
+  if (P.want_grad) plan_backward(P);
+  plan_gn_stats(P);
+}
+
+inline int guide_feat_dim(const dd_config& c) {
+  return c.guide_feature_dim > 0 ? c.guide_feature_dim : c.guide_planes[c.guide_stages - 1] * c.guide_expansion;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // sampler drivers
 // ---------------------------------------------------------------------------------------------------
@@ -1186,7 +1323,27 @@ void vae_fwd(dd_engine* E, int k, const float* x0, hipStream_t s) {
   run_fwd(E->vae, ctx);
 }
 
-// guide forward from the decoded image of instance k (bicubic -> resnet -> GAP) -> feat [B, D]
+// features of a finished guide forward -> feats [B, D] fp32: global average pool of the last feature map (ResNets, model_utils.py:31-33)
+// or the projected class token (ViT)
+void guide_features_out(dd_engine* E, const Ctx& gc, float* feats, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  const Tn& f = E->guide.t[E->guide_feat];
+  if (c.guide_kind == 1) HIPCHK(hipMemcpy2DAsync(feats, (size_t)f.C * 4, act_f32(gc, f), (size_t)f.ld * 4, (size_t)f.C * 4, f.rows, hipMemcpyDeviceToDevice, s));
+  else HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, feats, nullptr, c.max_batch, f.H * f.W, f.C, 0, s));
+}
+// cotangent of the features [B, D] fp32 -> gradient of the guide's output tensor (reverse of guide_features_out)
+void guide_features_grad_in(dd_engine* E, const Ctx& gc, const float* gfeat, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  const Tn& f = E->guide.t[E->guide_feat];
+  if (c.guide_kind == 1) {
+    if (f.ld != f.C) throw std::runtime_error("ViT guide: feature dim must be a multiple of 8");
+    HIPCHK(launch_f32_to_bf16(gfeat, grad_ptr(gc, f), (size_t)f.rows * f.C, s));
+  } else {
+    HIPCHK(launch_gap_bwd_f32(gfeat, grad_f32(gc, f), f.ld, c.max_batch, f.H * f.W, f.C, nullptr, s));
+  }
+}
+
+// guide forward from the decoded image of instance k (bicubic -> guide network -> features) -> feat [B, D]
 void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
   const dd_config& c = E->cfg;
   Run r{E, s, c.max_batch};
@@ -1199,8 +1356,7 @@ void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
     HIPCHK(launch_nchw_to_nhwc_f32(E->image_override, act_f32(vc, img), c.max_batch, c.vae_out_channels, img.H, img.W, img.ld, img.ld, s));
   HIPCHK(launch_bicubic_f32(act_f32(vc, img), img.ld, act_f32(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
   run_fwd(E->guide, gc);
-  const Tn& f = E->guide.t[E->guide_feat];
-  HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, E->inst[k].feat, nullptr, c.max_batch, f.H * f.W, f.C, 0, s));
+  guide_features_out(E, gc, E->inst[k].feat, s);
 }
 
 // reverse of guide_fwd_from_image + vae_fwd: gfeat -> g_x0 (fp32 NCHW)
@@ -1211,7 +1367,8 @@ void guide_vae_bwd(dd_engine* E, int k, float* g_x0, hipStream_t s) {
   Ctx vc = r.ctx(E->vae, E->inst[k].vae);
   const Tn& f = E->guide.t[E->guide_feat];
   // GAP^T; the ReLU mask of the last bottleneck is applied by that conv op's backward
-  HIPCHK(launch_gap_bwd_f32(E->inst[k].gfeat, grad_f32(gc, f), f.ld, c.max_batch, f.H * f.W, f.C, nullptr, s));
+  (void)f;
+  guide_features_grad_in(E, gc, E->inst[k].gfeat, s);
   run_bwd(E->guide, gc);
   const Tn& gin = E->guide.t[E->guide_in];
   const Tn& img = E->vae.t[E->vae_out];
@@ -1352,7 +1509,7 @@ int dd_finalize_weights(dd_engine* E) {
     const dd_config& c = E->cfg;
     build_unet(E);
     build_vae(E);
-    build_guide(E);
+    if (c.guide_kind == 1) build_guide_vit(E); else build_guide(E);
     const bool have_venc = E->has("vae", "encoder.conv_in.weight");
     const bool have_text = E->has("text", "text_model.embeddings.token_embedding.weight");
     if (have_venc) build_vae_encoder(E);
@@ -1378,8 +1535,8 @@ int dd_finalize_weights(dd_engine* E) {
         I.guide = (char*)E->dmalloc(E->guide.act_bytes);
       }
       I.z_in = (float*)E->dmalloc(zbytes); I.z_next = (float*)E->dmalloc(zbytes); I.x0 = (float*)E->dmalloc(zbytes);
-      I.feat = (float*)E->dmalloc((size_t)B * c.guide_planes[c.guide_stages - 1] * c.guide_expansion * 4);
-      I.gfeat = (float*)E->dmalloc((size_t)B * c.guide_planes[c.guide_stages - 1] * c.guide_expansion * 4);
+      I.feat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
+      I.gfeat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
     }
     if (c.enable_grad) {
       // UNet gradients alone; VAE and guide gradients live side by side (bicubic^T bridges them)
@@ -1610,8 +1767,7 @@ int dd_guide_encode(dd_engine* E, const float* images, float* feats, int B, void
     const Tn& gin = E->guide.t[E->guide_in];
     HIPCHK(launch_nchw_to_nhwc_f32(images, act_f32(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, s));
     run_fwd(E->guide, gc);
-    const Tn& f = E->guide.t[E->guide_feat];
-    HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, feats, nullptr, B, f.H * f.W, f.C, 0, s));
+    guide_features_out(E, gc, feats, s);
   });
 }
 
@@ -1780,8 +1936,7 @@ int dd_guide_vjp(dd_engine* E, const float* images, const float* g_feats, float*
     const Tn& gin = E->guide.t[E->guide_in];
     HIPCHK(launch_nchw_to_nhwc_f32(images, act_f32(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, s));
     run_fwd(E->guide, gc);
-    const Tn& f = E->guide.t[E->guide_feat];
-    HIPCHK(launch_gap_bwd_f32(g_feats, grad_f32(gc, f), f.ld, B, f.H * f.W, f.C, nullptr, s));
+    guide_features_grad_in(E, gc, g_feats, s);
     run_bwd(E->guide, gc);
     HIPCHK(launch_nhwc_to_nchw_f32(grad_f32(gc, gin), 1, g_images_out, B, 3, gin.H, gin.W, gin.ld, 1.f, 0.f, 0, 0.f, 0.f, s));
   });
@@ -1831,7 +1986,7 @@ int dd_debug_tensor(dd_engine* E, int prog_inst, int idx, int want_grad, float* 
     if (!want_grad && !slab) throw std::runtime_error("this instance has no slab for that program");
     char* base = want_grad ? E->grad_slab + t.goff : slab + t.off;
     const size_t n = (size_t)t.rows * t.ld;
-    if ((t.f32 && !want_grad) || (want_grad && P.f32)) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
+    if ((t.f32 && !want_grad) || (want_grad && t.gf32)) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
     else {
       std::vector<bf16_t> tmp(n);
       HIPCHK(hipMemcpy(tmp.data(), base, n * 2, hipMemcpyDeviceToHost));

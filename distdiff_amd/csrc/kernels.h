@@ -210,6 +210,17 @@ hipError_t launch_to_uint8(const float* nchw, uint8_t* hwc, int B, int C, int H,
 hipError_t launch_clip_embed(const int* ids, const float* tok, const float* pos, bf16_t* out, int ld, int rows, int T, int C, int vocab,
                             hipStream_t s);
 hipError_t launch_act_bf16(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, int kind, hipStream_t s);
+// the open_clip ViT guide (model_utils.py:80-87): GELU / quick_gelu backward, non-overlapping patch embedding as a GEMM (image fp32
+// NHWC -> rows [B*(S/p)^2, C*p*p], k = (c, iy, ix)) and its transpose, class token + positional embedding, class-token selection
+hipError_t launch_act_bwd_bf16(const bf16_t* x, int ldx, const bf16_t* dy, int ldd, bf16_t* dx, int ldo, int M, int C, int kind, int accumulate,
+                               hipStream_t s);
+hipError_t launch_patchify(const float* img, int ld, bf16_t* out, int B, int S, int p, int C, hipStream_t s);
+hipError_t launch_patchify_bwd(const bf16_t* gout, float* gimg, int ld, int B, int S, int p, int C, hipStream_t s);
+hipError_t launch_vit_embed(const bf16_t* patches, int ldp, const float* cls, const float* pos, bf16_t* out, int ldo, int B, int np, int W,
+                            hipStream_t s);
+hipError_t launch_vit_embed_bwd(const bf16_t* gout, int ldo, bf16_t* gp, int ldp, int B, int np, int W, hipStream_t s);
+hipError_t launch_select_rows(const bf16_t* x, int ldx, bf16_t* y, int ldy, int B, int stride, int C, hipStream_t s);
+hipError_t launch_select_rows_bwd(const bf16_t* dy, int ldy, bf16_t* dx, int ldx, int B, int stride, int C, int accumulate, hipStream_t s);
 hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
                              float scale, hipStream_t s);
 hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s);

@@ -30,6 +30,8 @@ class DDConfig(C.Structure):
         ("latent_size", C.c_int), ("text_len", C.c_int), ("max_batch", C.c_int),
         ("enable_grad", C.c_int), ("max_guidance_period", C.c_int),
         ("text_heads", C.c_int), ("text_act", C.c_int), ("text_eps", C.c_float),
+        ("guide_kind", C.c_int), ("guide_vit_heads", C.c_int), ("guide_vit_patch", C.c_int), ("guide_vit_act", C.c_int),
+        ("guide_feature_dim", C.c_int),
     ]
 
 
@@ -115,6 +117,9 @@ def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
     c.enable_grad, c.max_guidance_period = int(enable_grad), int(max_guidance_period)
     t = cfg.text
     c.text_heads, c.text_act, c.text_eps = t.num_attention_heads, {"quick_gelu": 0, "gelu": 1}[t.hidden_act], t.layer_norm_eps
+    c.guide_kind = 1 if g.kind == "vit" else 0
+    c.guide_vit_heads, c.guide_vit_patch, c.guide_vit_act = g.vit_heads, g.vit_patch, {"quick_gelu": 0, "gelu": 1}[g.vit_act]
+    c.guide_feature_dim = g.feature_dim
     return c
 
 

@@ -332,9 +332,14 @@ def load_config_and_weights(args, B):
     latent = args.resolution // 8
     if args.synthetic:
         cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
-        if args.arch in GUIDE_ARCHS:                 # -a resnext50 / wideresnet50: same Bottleneck program, other widths / groups
-            for k, v in GUIDE_ARCHS[args.arch].items():
-                setattr(cfg.guide, k, v)
+        if args.arch in GUIDE_ARCHS:                 # -a resnext50 / wideresnet50 / open_clip_vit_b32 (full-size guide only)
+            if args.tiny and GUIDE_ARCHS[args.arch].get("kind") == "vit":
+                cfg.guide.kind, cfg.guide.input_size = "vit", 64
+                cfg.guide.vit_width, cfg.guide.vit_layers, cfg.guide.vit_heads, cfg.guide.vit_mlp, cfg.guide.vit_out = 64, 2, 2, 128, 32
+                cfg.guide.vit_patch = 16
+            else:
+                for k, v in GUIDE_ARCHS[args.arch].items():
+                    setattr(cfg.guide, k, v)
             cfg.guide.arch = args.arch
         return cfg, synthetic_weights(cfg, seed=0, num_classes=args.synthetic_classes, encoders=args.synthetic_encode)
     path = args.pretrained_model_name_or_path
@@ -345,7 +350,10 @@ def load_config_and_weights(args, B):
     arch = args.arch if (args.guidance_type or args.arch in SUPPORTED) else "resnet50"   # unguided runs never evaluate the guide
     cfg.guide = guide_config(arch)
     guide = create_model(arch, pretrained=False, num_classes=1, weight_path=args.encoder_weight_path if args.guidance_type else None)
-    weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": guide.state_dict(),
+    gsd = guide.state_dict()
+    if cfg.guide.kind == "vit":                   # the CLIP checkpoint also carries the text tower: only the image tower is on this path
+        gsd = {k: v for k, v in gsd.items() if k.startswith("visual.")}
+    weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": gsd,
                "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder").items() if "position_ids" not in k}}
     return cfg, weights
 

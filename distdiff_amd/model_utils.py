@@ -3,8 +3,9 @@
 `forward(x) -> logits`, `.eval() / .float() / .to() / .cuda()`, and loads `{'state_dict': ...}` checkpoints with an optional
 `module.` prefix (model_utils.py:89-101). The arithmetic runs in the engine's guide program (BN folded, exact fp32 on v_mfma_f32_32x32x2_f32, guide_f32.hip).
 Built: the three timm Bottleneck networks of the reference -- resnet50 (model_utils.py:47-55), resnext50 = resnext50_32x4d (:56-63,
-grouped 3x3 convolutions) and wideresnet50 = wide_resnet50_2 (:72-79); the engine reads widths and groups from the weight shapes.
-mobilenetv2 (:64-71) and open_clip_vit_b32 (:80-87) are different network families and raise NotImplementedError."""
+grouped 3x3 convolutions) and wideresnet50 = wide_resnet50_2 (:72-79); the engine reads widths and groups from the weight shapes --
+and open_clip_vit_b32 (:80-87, the reference's default --arch): encode_image = the open_clip image tower (bf16 program, `visual.*` keys).
+mobilenetv2 (:64-71) raises NotImplementedError."""
 import torch
 
 from .weights import load_guide_checkpoint, synthetic_guide
@@ -65,7 +66,7 @@ class GuideModel:
         return torch.cat(outs)
 
     def forward(self, x):
-        f = self.encode_image(x)
+        f = self.encode_image(x)                  # CLIP: wrap_clip_forward's `fc(encode_image(x))` (model_utils.py:14-26)
         w, b = self._sd["fc.weight"].to(f.device), self._sd["fc.bias"].to(f.device)
         return torch.nn.functional.linear(f, w, b)   # classifier head: not on the expansion hot path
 
@@ -76,8 +77,7 @@ def create_model(model_name, num_classes=1000, pretrained=False, class_names=Non
                  weight_path=None, cfg=None):
     print("=> creating model '{}'".format(model_name))
     if model_name not in SUPPORTED:
-        raise NotImplementedError("guide arch %r is not built (built: %s; mobilenetv2 and open_clip_vit_b32 are other network "
-                                  "families, SURVEY.md section 8f-4)" % (model_name, ", ".join(SUPPORTED)))
+        raise NotImplementedError("guide arch %r is not built (built: %s; SURVEY.md section 8f-4)" % (model_name, ", ".join(SUPPORTED)))
     from .config import guide_config, sd15_config
     if cfg is None:
         cfg = sd15_config()

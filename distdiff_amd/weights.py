@@ -218,8 +218,36 @@ def synthetic_text_encoder(cfg: EngineConfig, seed=0):
     return b.sd
 
 
+def synthetic_guide_vit(cfg: EngineConfig, seed=0, num_classes=100):
+    """open_clip VisionTransformer state dict (`visual.*` keys of the CLIP model the reference builds at model_utils.py:80-87)."""
+    g = cfg.guide
+    b = _Builder("guide.", seed)
+    W, v = g.vit_width, "visual."
+    b.conv(v + "conv1", W, 3, g.vit_patch, bias=False)
+    n_tok = (g.input_size // g.vit_patch) ** 2 + 1
+    sc = W ** -0.5
+    b.sd[v + "class_embedding"] = _randn("guide.cls", (W,), sc, seed)
+    b.sd[v + "positional_embedding"] = _randn("guide.pos", (n_tok, W), sc, seed)
+    b.norm(v + "ln_pre", W)
+    for l in range(g.vit_layers):
+        r = v + "transformer.resblocks.%d" % l
+        b.norm(r + ".ln_1", W)
+        b.sd[r + ".attn.in_proj_weight"] = _randn("guide." + r + ".qkv.w", (3 * W, W), 1.0 / math.sqrt(W), seed)
+        b.sd[r + ".attn.in_proj_bias"] = _randn("guide." + r + ".qkv.b", (3 * W,), 0.02, seed)
+        b.linear(r + ".attn.out_proj", W, W)
+        b.norm(r + ".ln_2", W)
+        b.linear(r + ".mlp.c_fc", g.vit_mlp, W)
+        b.linear(r + ".mlp.c_proj", W, g.vit_mlp)
+    b.norm(v + "ln_post", W)
+    b.sd[v + "proj"] = _randn("guide.proj", (W, g.vit_out), sc, seed)
+    b.linear("fc", num_classes, g.vit_out)      # wrap_clip_forward's text-feature classifier head (model_utils.py:14-26): not on the hot path
+    return b.sd
+
+
 def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
     g = cfg.guide
+    if g.kind == "vit":
+        return synthetic_guide_vit(cfg, seed, num_classes)
     b = _Builder("guide.", seed)
     b.conv("conv1", g.stem_channels, 3, 7, bias=False)
     b.bn("bn1", g.stem_channels)

@@ -70,6 +70,12 @@ typedef struct dd_config {
   int text_heads;       /* num_attention_heads (0: 12) */
   int text_act;         /* hidden_act: 0 quick_gelu (SD-1.x), 1 gelu */
   float text_eps;       /* layer_norm_eps (0: 1e-5) */
+  /* guide model family: 0 = timm Bottleneck ResNets (resnet50 / resnext50_32x4d / wide_resnet50_2, exact fp32), 1 = the image tower of
+   * an open_clip ViT (open_clip_vit_b32, model_utils.py:80-87; bf16 MFMA): width, depth and MLP size come from the state dict */
+  int guide_kind;
+  int guide_vit_heads, guide_vit_patch;
+  int guide_vit_act;    /* 0 quick_gelu, 1 gelu (open_clip 'ViT-B-32': gelu) */
+  int guide_feature_dim; /* D of encode_image: 2048 (ResNets) / 512 (ViT-B/32 projection) */
 } dd_config;
 
 typedef struct dd_sampler_params {

@@ -331,6 +331,38 @@ class GuideOracle:
         return torch.flatten(f, 1)
 
 
+class GuideOracleViT:
+    """open_clip VisionTransformer.forward (image tower of 'ViT-B-32'; `model.encode_image` of the CLIP guide, model_utils.py:80-87),
+    restated from the published open_clip definition (open_clip is not installed: unpinned like the other third-party modules):
+    conv1 -> [class_embedding; patches] + positional_embedding -> ln_pre -> residual attention blocks (nn.MultiheadAttention with the
+    fused in_proj, MLP c_fc -> GELU -> c_proj) -> ln_post -> class token -> @ proj."""
+
+    def __init__(self, cfg: EngineConfig, sd):
+        self.cfg, self.sd = cfg, sd
+
+    def encode_image(self, x, pooling="avg"):
+        g, sd, v = self.cfg.guide, self.sd, "visual."
+        W, H = g.vit_width, g.vit_heads
+        x = F.conv2d(x, sd[v + "conv1.weight"], None, stride=g.vit_patch)
+        B = x.shape[0]
+        x = x.reshape(B, W, -1).permute(0, 2, 1)
+        x = torch.cat([sd[v + "class_embedding"].to(x.dtype).expand(B, 1, -1), x], dim=1) + sd[v + "positional_embedding"]
+        x = F.layer_norm(x, (W,), sd[v + "ln_pre.weight"], sd[v + "ln_pre.bias"], 1e-5)
+        act = F.gelu if g.vit_act == "gelu" else (lambda t: t * torch.sigmoid(1.702 * t))
+        for l in range(g.vit_layers):
+            r = v + "transformer.resblocks.%d" % l
+            n = F.layer_norm(x, (W,), sd[r + ".ln_1.weight"], sd[r + ".ln_1.bias"], 1e-5)
+            qkv = F.linear(n, sd[r + ".attn.in_proj_weight"], sd[r + ".attn.in_proj_bias"])
+            q, k, vv = (t.reshape(B, -1, H, W // H).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+            a = F.scaled_dot_product_attention(q, k, vv).transpose(1, 2).reshape(B, -1, W)
+            x = x + F.linear(a, sd[r + ".attn.out_proj.weight"], sd[r + ".attn.out_proj.bias"])
+            n = F.layer_norm(x, (W,), sd[r + ".ln_2.weight"], sd[r + ".ln_2.bias"], 1e-5)
+            x = x + F.linear(act(F.linear(n, sd[r + ".mlp.c_fc.weight"], sd[r + ".mlp.c_fc.bias"])), sd[r + ".mlp.c_proj.weight"],
+                             sd[r + ".mlp.c_proj.bias"])
+        pooled = F.layer_norm(x[:, 0], (W,), sd[v + "ln_post.weight"], sd[v + "ln_post.bias"], 1e-5)
+        return pooled @ sd[v + "proj"]
+
+
 # ------------------------------------------------------------------------------------------------
 # Sampler: restatement of generate_data.py:109-137, 687-767, 1161-1228
 # ------------------------------------------------------------------------------------------------
@@ -479,5 +511,5 @@ def expand_one(args, cfg, models, image_latents, noise, e, b, prompt_embeds, neg
 
 
 def build_models(cfg, weights):
-    return (UNetOracle(cfg, weights["unet"]), VAEOracle(cfg, weights["vae"]), GuideOracle(cfg, weights["guide"]),
-            DDIMSchedulerOracle(cfg))
+    guide = (GuideOracleViT if cfg.guide.kind == "vit" else GuideOracle)(cfg, weights["guide"])
+    return (UNetOracle(cfg, weights["unet"]), VAEOracle(cfg, weights["vae"]), guide, DDIMSchedulerOracle(cfg))

@@ -139,3 +139,73 @@ def test_bicubic_maxpool_gap_f32(hip_lib):
     gi = F.interpolate(img, size=(cfg.guide.input_size,) * 2, mode="bicubic")
     assert rel(eng.guide_encode(gi), guide.encode_image(gi)) < 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["tiny_vit", "open_clip_vit_b32"])
+def test_clip_vit_guide_forward_and_vjp_vs_oracle(hip_lib, which):
+    """The reference's default guide, `--arch open_clip_vit_b32` (model_utils.py:80-87): encode_image = the open_clip image tower.  No ReLU
+    masks: a bf16 program like the UNet (LayerNorm / fused-QKV attention / GELU MLP kernels), tolerance 3 % forward, 5 % VJP."""
+    from distdiff_amd.config import GuideConfig, guide_config, sd15_config, tiny_config
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    B = 2
+    if which == "tiny_vit":
+        cfg = tiny_config(max_batch=B)
+        cfg.guide = GuideConfig(kind="vit", input_size=64, vit_width=64, vit_layers=2, vit_heads=2, vit_patch=16, vit_mlp=128, vit_out=32)
+    else:
+        cfg = sd15_config(latent_size=8, max_batch=B)
+        cfg.guide = guide_config(which)
+    w = synthetic_weights(cfg, seed=0, num_classes=5)
+    eng = _engine(cfg, w, B)
+    guide = O.GuideOracleViT(cfg, w["guide"])
+    S = cfg.guide.input_size
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, S, S, generator=g) * 0.5
+    gf = torch.randn(B, cfg.guide.feature_dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    f_ref = guide.encode_image(xr)
+    (g_ref,) = torch.autograd.grad(f_ref, xr, gf)
+    assert rel(eng.guide_encode(x), f_ref.detach()) < 0.03
+    assert rel(eng.guide_vjp(x, gf), g_ref) < 0.05
+    eng.close()
+
+
+def test_clip_vit_guided_step_vs_oracle(hip_lib):
+    """transform_guidance through the ViT guide on the tiny UNet / VAE: score and (e, b) gradients against the oracle (the ViT has no
+    masks, so the comparison at the oracle's own forward point is meaningful: <= 8 %)."""
+    from distdiff_amd.config import GuideConfig, tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    B = 2
+    cfg = tiny_config(max_batch=B)
+    cfg.guide = GuideConfig(kind="vit", input_size=64, vit_width=64, vit_layers=2, vit_heads=2, vit_patch=16, vit_mlp=128, vit_out=32)
+    w = synthetic_weights(cfg, seed=0, num_classes=5)
+    eng = Engine(cfg, w, enable_grad=True, max_guidance_period=2)
+    sched = DDIMSchedule(cfg.scheduler)
+    ts = sched.set_timesteps(10)
+    eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_period=2)
+    g = torch.Generator().manual_seed(2)
+    L, D = cfg.latent_size, cfg.guide.feature_dim
+    z = torch.randn(B, 4, L, L, generator=g)
+    e, b = torch.rand(B, 4, 1, 1, generator=g), torch.randn(B, 4, 1, 1, generator=g) * 0.3
+    pe = torch.randn(B, cfg.text_len, cfg.unet.cross_attention_dim, generator=g)
+    ne = torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g).expand(B, -1, -1)
+    Pc = F.normalize(torch.randn(5, D, generator=g), dim=-1)
+    Pg = F.normalize(torch.randn(5, 3, D, generator=g), dim=-1)
+    tg = torch.tensor([1, 3])
+    eng.set_prototypes(Pc, Pg)
+    eng.set_prompt(torch.cat([ne, pe]).cuda())
+    zn, score, gz0 = eng.transform_guidance(z, tg, e, b, 5, 2)
+    unet, vae, guide, so = O.build_models(cfg, w)
+    tso = so.set_timesteps(10)
+    args = O.SamplerArgs(guidance_type="transform_guidance", num_inference_steps=10, guidance_step=5, guidance_period=2)
+    zr, sr, (ge, gb) = O.transform_guidance(args, z, tg, [int(tso[5]), int(tso[6])], so, unet, torch.cat([ne, pe]), vae, guide, e, b, Pc, Pg,
+                                            cfg.guide.input_size)
+    assert abs(score.item() - float(sr)) < 0.01 * abs(float(sr))
+    ge_h = (gz0.cpu() * z).sum((2, 3), keepdim=True)
+    gb_h = gz0.cpu().sum((2, 3), keepdim=True)
+    assert rel(ge_h, ge) < 0.08 and rel(gb_h, gb) < 0.08, (rel(ge_h, ge), rel(gb_h, gb))
+    assert rel(zn, zr) < 0.05
+    eng.close()
