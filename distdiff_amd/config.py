@@ -77,22 +77,35 @@ class GuideConfig:
     vit_mlp: int = 3072
     vit_out: int = 512
     vit_act: str = "gelu"
+    # kind "mbv2": timm mobilenetv2_100 (model_utils.py:64-71): stem 32, stages (out channels, repeats, first stride), expansion 6
+    # from stage 1 on (stage 0 is a depthwise-separable block), conv_head 1280
+    mb_stem: int = 32
+    mb_channels: Tuple[int, ...] = (16, 24, 32, 64, 96, 160, 320)
+    mb_repeats: Tuple[int, ...] = (1, 2, 3, 4, 3, 3, 1)
+    mb_strides: Tuple[int, ...] = (1, 2, 2, 2, 1, 2, 1)
+    mb_expand: int = 6
+    mb_head: int = 1280
 
     @property
     def feature_dim(self):
-        return self.vit_out if self.kind == "vit" else self.planes[-1] * self.expansion
+        if self.kind == "vit":
+            return self.vit_out
+        if self.kind == "mbv2":
+            return self.mb_head
+        return self.planes[-1] * self.expansion
 
     def width(self, planes):
         return int(planes * self.base_width / 64) * self.cardinality
 
 
-# the reference's guide architectures (model_utils.py:47-87): the three timm Bottleneck ResNets (exact fp32 program) and the open_clip
-# ViT-B/32 image tower (bf16 program); mobilenetv2 (:64-71) is not built
+# the reference's five guide architectures (model_utils.py:47-87): the three timm Bottleneck ResNets and mobilenetv2_100 (exact fp32
+# programs: ReLU / ReLU6 masks) and the open_clip ViT-B/32 image tower (bf16 program)
 GUIDE_ARCHS = {
     "resnet50": dict(cardinality=1, base_width=64),
     "resnext50": dict(cardinality=32, base_width=4),          # timm resnext50_32x4d
     "wideresnet50": dict(cardinality=1, base_width=128),      # timm wide_resnet50_2
     "open_clip_vit_b32": dict(kind="vit"),                    # open_clip 'ViT-B-32' image tower (the reference's default --arch)
+    "mobilenetv2": dict(kind="mbv2"),                         # timm mobilenetv2_100
 }
 
 

@@ -236,6 +236,12 @@ struct dd_engine {
   size_t total_bytes = 0;
   double flops = 0;
   Profiler prof;
+  // hipGraph replay of the plain denoise step (~700 launches): one captured graph per (timestep index, latent buffers); the bias
+  // tables / DDIM coefficients of a step and every workspace pointer are static, so a step is the same launch sequence every time
+  struct StepGraph { hipGraphExec_t exec = nullptr; double flops = 0; int seen = 0; };
+  std::unordered_map<std::string, StepGraph> step_graphs;
+  hipStream_t gstream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool graphs_ok = true;
 
   void dfree(void* p) {
     if (!p) return;
@@ -277,6 +283,10 @@ struct dd_engine {
 };
 
 namespace {
+
+inline int guide_feat_dim_decl(const dd_config& c) {
+  return c.guide_feature_dim > 0 ? c.guide_feature_dim : c.guide_planes[c.guide_stages - 1] * c.guide_expansion;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // weight construction
@@ -661,7 +671,8 @@ void run_conv_f32_fwd(const Program& P, const Op& op, const Ctx& c) {
   p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.M = y.rows;
   if (w->bias) { p.flags |= CF_BIAS; p.bias = w->bias; }
   if (op.res >= 0) { p.flags |= CF_RES; p.res = act_f32(c, P.t[op.res]); p.res_ld = P.t[op.res].ld; }
-  if (op.relu) p.flags |= CF_RELU;
+  if (op.relu == 1) p.flags |= CF_RELU;
+  if (op.relu == 2) p.flags |= CF_RELU6;
   HIPCHK(launch_conv_f32(p, c.s));
 }
 
@@ -670,7 +681,7 @@ void run_conv_f32_bwd(const Program& P, const Op& op, const Ctx& c) {
   const ConvW* w = op.cw;
   float* gy = grad_f32(c, y);
   // ReLU mask from the fp32 forward output (y > 0), then the residual fan-out, then the dgrad GEMM
-  if (op.relu) HIPCHK(launch_mask_f32(gy, y.ld, act_f32(c, y), y.ld, gy, y.ld, y.rows, rup(y.C, 4), c.s));
+  if (op.relu) HIPCHK(launch_mask_f32(gy, y.ld, act_f32(c, y), y.ld, gy, y.ld, y.rows, rup(y.C, 4), op.relu == 2 ? 6.f : 0.f, c.s));
   if (op.res >= 0 && P.t[op.res].grad) {
     const Tn& r = P.t[op.res];
     if (op.res_acc) HIPCHK(launch_add_f32(grad_f32(c, r), r.ld, gy, y.ld, grad_f32(c, r), r.ld, r.rows, rup(r.C, 4), c.s));
@@ -1208,6 +1219,49 @@ void build_guide(dd_engine* E) {
   plan_gn_stats(P);
 }
 
+// timm mobilenetv2_100 (model_utils.py:64-71) forward_features: conv_stem/bn1/ReLU6 -> blocks (stage 0: DepthwiseSeparableConv = conv_dw, bn1,
+// ReLU6, conv_pw, bn2; later stages: InvertedResidual = conv_pw, bn1, ReLU6, conv_dw (stride), bn2, ReLU6, conv_pwl, bn3, + x when the
+// stride is 1 and the channel count is unchanged) -> conv_head, bn2, ReLU6.  Exact fp32 like the ResNets (ReLU6 masks); depthwise
+// convolutions are grouped convolutions with one channel per group (block-diagonal packing, K-steps outside the groups skipped).
+void build_guide_mbv2(dd_engine* E) {
+  const dd_config& c = E->cfg;
+  Program& P = E->guide;
+  P.want_grad = c.enable_grad != 0;
+  P.f32 = true;
+  Builder b(E, P);
+  const std::string m = "guide";
+  const int B = c.max_batch, S = c.guide_input_size;
+  const float eps = c.guide_bn_eps;
+  E->guide_in = P.tensor(B, S, S, 3);
+  int h = b.conv(E->guide_in, make_conv_bn(E, m, "conv_stem", "bn1", 1, eps, 3), 2, 0, -1, /*relu6=*/2);
+  char buf[128];
+  for (int s = 0; s < c.guide_stages; ++s)
+    for (int bi = 0; bi < c.guide_blocks[s]; ++bi) {
+      const int stride = bi == 0 ? c.guide_strides[s] : 1;
+      snprintf(buf, sizeof buf, "blocks.%d.%d", s, bi);
+      const std::string p = buf;
+      const int x = h;
+      int o;
+      if (E->has(m, p + ".conv_pwl.weight")) {
+        o = b.conv(x, make_conv_bn(E, m, p + ".conv_pw", p + ".bn1", 0, eps, P.t[x].C), 1, 0, -1, 2);
+        o = b.conv(o, make_conv_bn(E, m, p + ".conv_dw", p + ".bn2", 1, eps, P.t[o].C), stride, 0, -1, 2);
+        const HostTensor& wl = E->get(m, p + ".conv_pwl.weight");
+        const bool skip = stride == 1 && (int)wl.shape[0] == P.t[x].C;
+        h = b.conv(o, make_conv_bn(E, m, p + ".conv_pwl", p + ".bn3", 0, eps, P.t[o].C), 1, 0, skip ? x : -1, 0);
+      } else {
+        o = b.conv(x, make_conv_bn(E, m, p + ".conv_dw", p + ".bn1", 1, eps, P.t[x].C), stride, 0, -1, 2);
+        const HostTensor& wp = E->get(m, p + ".conv_pw.weight");
+        const bool skip = stride == 1 && (int)wp.shape[0] == P.t[x].C;
+        h = b.conv(o, make_conv_bn(E, m, p + ".conv_pw", p + ".bn2", 0, eps, P.t[o].C), 1, 0, skip ? x : -1, 0);
+      }
+    }
+  h = b.conv(h, make_conv_bn(E, m, "conv_head", "bn2", 0, eps, P.t[h].C), 1, 0, -1, 2);
+  E->guide_feat = h;
+  if (P.t[h].C != guide_feat_dim_decl(c)) throw std::runtime_error("mobilenetv2 guide: conv_head width != guide_feature_dim");
+  if (P.want_grad) plan_backward(P);
+  plan_gn_stats(P);
+}
+
 // open_clip VisionTransformer (the image tower behind `image_encoder.encode_image` when --arch open_clip_vit_b32, the reference's default
 // guide; model_utils.py:80-87): conv1 (stride = kernel = patch, no bias) -> [class_embedding; patches] + positional_embedding -> ln_pre ->
 // residual attention blocks (ln_1 -> nn.MultiheadAttention (fused in_proj) -> +x ; ln_2 -> c_fc -> GELU -> c_proj -> +x) -> ln_post on
@@ -1440,6 +1494,10 @@ int dd_create(const dd_config* cfg, dd_engine** out) {
 
 void dd_destroy(dd_engine* e) {
   if (!e) return;
+  for (auto& kv : e->step_graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+  if (e->gstream) hipStreamDestroy(e->gstream);
+  if (e->ev_in) hipEventDestroy(e->ev_in);
+  if (e->ev_out) hipEventDestroy(e->ev_out);
   for (void* p : e->dev_allocs) hipFree(p);
   delete e;
 }
@@ -1509,7 +1567,9 @@ int dd_finalize_weights(dd_engine* E) {
     const dd_config& c = E->cfg;
     build_unet(E);
     build_vae(E);
-    if (c.guide_kind == 1) build_guide_vit(E); else build_guide(E);
+    if (c.guide_kind == 1) build_guide_vit(E);
+    else if (c.guide_kind == 2) build_guide_mbv2(E);
+    else build_guide(E);
     const bool have_venc = E->has("vae", "encoder.conv_in.weight");
     const bool have_text = E->has("text", "text_model.embeddings.token_embedding.weight");
     if (have_venc) build_vae_encoder(E);
@@ -1688,17 +1748,69 @@ int dd_unet_forward(dd_engine* E, const float* z, int step_index, float* eps2_ou
   });
 }
 
+// the launch sequence of one plain step: UNet forward (no stash) + CFG + DDIM
+static void denoise_step_enqueue(dd_engine* E, const float* z, int step_index, float* z_prev_out, float* x0_out, hipStream_t s) {
+  const dd_config& c = E->cfg;
+  unet_fwd(E, 0, z, step_index, s, /*stash=*/false);
+  const Tn& out = E->unet.t[E->unet_out];
+  HIPCHK(launch_cfg_ddim((const float*)(E->inst[0].unet + out.off), out.ld, z, z_prev_out, x0_out, c.max_batch, c.unet_out_channels,
+                         c.latent_size * c.latent_size, E->coef_table + (size_t)step_index * 8, s));
+}
+
 int dd_denoise_step(dd_engine* E, const float* z, int step_index, float* z_prev_out, float* x0_out, int B, void* stream) {
   if (!E || !z || !z_prev_out) return DD_ERR_ARG;
   DD_TRY(E, {
     check_batch(E, B);
     if (step_index < 0 || step_index >= (int)E->timesteps.size()) throw std::runtime_error("step_index out of range");
-    const dd_config& c = E->cfg;
     hipStream_t s = (hipStream_t)stream;
-    unet_fwd(E, 0, z, step_index, s, /*stash=*/false);
-    const Tn& out = E->unet.t[E->unet_out];
-    HIPCHK(launch_cfg_ddim((const float*)(E->inst[0].unet + out.off), out.ld, z, z_prev_out, x0_out, B, c.unet_out_channels,
-                           c.latent_size * c.latent_size, E->coef_table + (size_t)step_index * 8, s));
+    // Opt-in (DD_GRAPH=1): measured on MI355X the replay does not pay -- B = 16: 1485 vs 1481 ms per batch, B = 1: 313 vs 302 ms
+    // (DESIGN.md section 6): even at B = 1 the ~6300 launches of an image are GPU-bound small kernels, not launch-bound.
+    static const bool use_graph = getenv("DD_GRAPH") != nullptr && atoi(getenv("DD_GRAPH")) != 0;
+    if (!use_graph || !E->graphs_ok || E->prof.on) { denoise_step_enqueue(E, z, step_index, z_prev_out, x0_out, s); return DD_OK; }
+    // first sighting of a (step, buffers) key: plain launches (also runs every one-time hipFuncSetAttribute); second: capture on the
+    // engine's own stream (the caller's may be the legacy default stream, which cannot be captured) and instantiate; then replay
+    char key[96];
+    snprintf(key, sizeof key, "%d/%p/%p/%p", step_index, (const void*)z, (void*)z_prev_out, (void*)x0_out);
+    auto it = E->step_graphs.find(key);
+    if (it == E->step_graphs.end()) {
+      if (E->step_graphs.size() >= 256) { denoise_step_enqueue(E, z, step_index, z_prev_out, x0_out, s); return DD_OK; }
+      dd_engine::StepGraph g;
+      const double f0 = E->flops;
+      denoise_step_enqueue(E, z, step_index, z_prev_out, x0_out, s);
+      g.flops = E->flops - f0; g.seen = 1;
+      E->step_graphs[key] = g;
+      return DD_OK;
+    }
+    dd_engine::StepGraph& g = it->second;
+    if (!E->gstream) {
+      HIPCHK(hipStreamCreateWithFlags(&E->gstream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&E->ev_in, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&E->ev_out, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(E->ev_in, s));
+    HIPCHK(hipStreamWaitEvent(E->gstream, E->ev_in, 0));
+    if (!g.exec) {
+      hipGraph_t graph = nullptr;
+      const double f0 = E->flops;
+      bool ok = hipStreamBeginCapture(E->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        try { denoise_step_enqueue(E, z, step_index, z_prev_out, x0_out, E->gstream); } catch (...) { ok = false; }
+        ok = (hipStreamEndCapture(E->gstream, &graph) == hipSuccess) && ok && graph;
+      }
+      E->flops = f0;
+      if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (!ok) {   // capture is an optimisation only: fall back to plain launches for good
+        (void)hipGetLastError();
+        g.exec = nullptr; E->graphs_ok = false;
+        denoise_step_enqueue(E, z, step_index, z_prev_out, x0_out, s);
+        return DD_OK;
+      }
+    }
+    HIPCHK(hipGraphLaunch(g.exec, E->gstream));
+    E->flops += g.flops;
+    HIPCHK(hipEventRecord(E->ev_out, E->gstream));
+    HIPCHK(hipStreamWaitEvent(s, E->ev_out, 0));
   });
 }
 

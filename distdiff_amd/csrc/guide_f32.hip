@@ -150,6 +150,10 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Params p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) h[q] = fmaxf(h[q], 0.f);
     }
+    if (flags & CF_RELU6) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = fminf(fmaxf(h[q], 0.f), 6.f);
+    }
     if (flags & CF_MASK) {
       const float* mp = p.mask + (size_t)m * p.mask_ld + nb;
 #pragma unroll
@@ -182,15 +186,16 @@ __global__ void add_f32_kernel(const float* a, int lda, const float* b, int ldb,
     st4(y + m * ldy + vc * 4, x);
   }
 }
-// y = dy * (mask > 0)
-__global__ void mask_f32_kernel(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C) {
+// y = dy * (mask > 0 && mask < hi)   (hi = +inf: ReLU; 6: ReLU6 = hardtanh(0, 6), whose gradient is 1 strictly inside the interval)
+__global__ void mask_f32_kernel(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, float hi) {
   const int VC = C >> 2;
   GRID_STRIDE(i, (size_t)M * VC) {
     const int vc = (int)(i % VC);
     const size_t m = i / VC;
     float4 x = ld4(dy + m * ldd + vc * 4);
     const float4 z = ld4(mask + m * ldm + vc * 4);
-    x.x = z.x > 0.f ? x.x : 0.f; x.y = z.y > 0.f ? x.y : 0.f; x.z = z.z > 0.f ? x.z : 0.f; x.w = z.w > 0.f ? x.w : 0.f;
+    x.x = (z.x > 0.f && z.x < hi) ? x.x : 0.f; x.y = (z.y > 0.f && z.y < hi) ? x.y : 0.f;
+    x.z = (z.z > 0.f && z.z < hi) ? x.z : 0.f; x.w = (z.w > 0.f && z.w < hi) ? x.w : 0.f;
     st4(y + m * ldy + vc * 4, x);
   }
 }
@@ -384,8 +389,8 @@ hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, floa
 hipError_t launch_copy_f32(const float* a, int lda, float* y, int ldy, int M, int C, hipStream_t s) {
   LAUNCH(add_f32_kernel, (size_t)M * (C / 4), a, lda, (const float*)nullptr, 0, y, ldy, M, C);
 }
-hipError_t launch_mask_f32(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, hipStream_t s) {
-  LAUNCH(mask_f32_kernel, (size_t)M * (C / 4), dy, ldd, mask, ldm, y, ldy, M, C);
+hipError_t launch_mask_f32(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, float hi, hipStream_t s) {
+  LAUNCH(mask_f32_kernel, (size_t)M * (C / 4), dy, ldd, mask, ldm, y, ldy, M, C, hi > 0.f ? hi : INFINITY);
 }
 hipError_t launch_maxpool3x3s2_f32(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
   LAUNCH(maxpool_f32_kernel, (size_t)B * (H / 2) * (W / 2) * (C / 4), x, y, B, H, W, C);

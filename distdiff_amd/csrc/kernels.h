@@ -22,6 +22,7 @@ enum ConvFlags {
   CF_MASK = 32,      // multiply by (mask[m, n] > 0)   (ReLU backward)
   CF_RES_F32 = 64,   // residual is fp32
   CF_GEGLU_RAW = 128,// with CF_GEGLU: also store the raw packed pre-activation (bf16) to raw[m, N]
+  CF_RELU6 = 512,    // min(max(., 0), 6)   (fp32 guide kernels: MobileNetV2)
   CF_STATS = 256     // also emit per-(64-row block, output channel) partial statistics (mean, M2) of the stored values: the
                      // GroupNorm that consumes this tensor then needs no statistics pass of its own (conv_gemm_can_emit_stats)
 };
@@ -247,7 +248,8 @@ struct ConvF32Params {
 hipError_t launch_conv_f32(const ConvF32Params& p, hipStream_t s);
 hipError_t launch_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int M, int C, hipStream_t s);
 hipError_t launch_copy_f32(const float* a, int lda, float* y, int ldy, int M, int C, hipStream_t s);
-hipError_t launch_mask_f32(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, hipStream_t s);
+// y = dy * (mask > 0 [&& mask < hi when hi > 0])   (ReLU / ReLU6 backward from the stored forward output)
+hipError_t launch_mask_f32(const float* dy, int ldd, const float* mask, int ldm, float* y, int ldy, int M, int C, float hi, hipStream_t s);
 hipError_t launch_maxpool3x3s2_f32(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t s);
 // src fp32 NHWC [B,Hs,Ws,ld_s] -> dst fp32 [B,Hd,Wd,ld_d]; the transpose writes bf16 rows (dsrc_bf16) or fp32

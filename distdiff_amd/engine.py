@@ -30,7 +30,7 @@ class DDConfig(C.Structure):
         ("latent_size", C.c_int), ("text_len", C.c_int), ("max_batch", C.c_int),
         ("enable_grad", C.c_int), ("max_guidance_period", C.c_int),
         ("text_heads", C.c_int), ("text_act", C.c_int), ("text_eps", C.c_float),
-        ("guide_kind", C.c_int), ("guide_vit_heads", C.c_int), ("guide_vit_patch", C.c_int), ("guide_vit_act", C.c_int),
+        ("guide_kind", C.c_int), ("guide_strides", _IA), ("guide_vit_heads", C.c_int), ("guide_vit_patch", C.c_int), ("guide_vit_act", C.c_int),
         ("guide_feature_dim", C.c_int),
     ]
 
@@ -117,7 +117,11 @@ def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
     c.enable_grad, c.max_guidance_period = int(enable_grad), int(max_guidance_period)
     t = cfg.text
     c.text_heads, c.text_act, c.text_eps = t.num_attention_heads, {"quick_gelu": 0, "gelu": 1}[t.hidden_act], t.layer_norm_eps
-    c.guide_kind = 1 if g.kind == "vit" else 0
+    c.guide_kind = {"resnet": 0, "vit": 1, "mbv2": 2}[g.kind]
+    if g.kind == "mbv2":
+        c.guide_stem, c.guide_stages = g.mb_stem, len(g.mb_channels)
+        c.guide_planes, c.guide_blocks, c.guide_strides = arr(g.mb_channels), arr(g.mb_repeats), arr(g.mb_strides)
+        c.guide_expansion = g.mb_expand
     c.guide_vit_heads, c.guide_vit_patch, c.guide_vit_act = g.vit_heads, g.vit_patch, {"quick_gelu": 0, "gelu": 1}[g.vit_act]
     c.guide_feature_dim = g.feature_dim
     return c
@@ -150,7 +154,7 @@ class Engine:
             self.layout = []
             for model in ("unet", "vae", "guide", "text"):
                 for key, t in weights.get(model, {}).items():
-                    if key.startswith("fc.") or key.endswith("num_batches_tracked"):
+                    if key.startswith(("fc.", "classifier.")) or key.endswith("num_batches_tracked"):
                         continue
                     a = t.detach().float().contiguous().cpu()
                     shape = (C.c_int64 * a.dim())(*a.shape)

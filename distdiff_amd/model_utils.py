@@ -4,8 +4,8 @@
 `module.` prefix (model_utils.py:89-101). The arithmetic runs in the engine's guide program (BN folded, exact fp32 on v_mfma_f32_32x32x2_f32, guide_f32.hip).
 Built: the three timm Bottleneck networks of the reference -- resnet50 (model_utils.py:47-55), resnext50 = resnext50_32x4d (:56-63,
 grouped 3x3 convolutions) and wideresnet50 = wide_resnet50_2 (:72-79); the engine reads widths and groups from the weight shapes --
-and open_clip_vit_b32 (:80-87, the reference's default --arch): encode_image = the open_clip image tower (bf16 program, `visual.*` keys).
-mobilenetv2 (:64-71) raises NotImplementedError."""
+open_clip_vit_b32 (:80-87, the reference's default --arch): encode_image = the open_clip image tower (bf16 program, `visual.*` keys);
+and mobilenetv2 = timm mobilenetv2_100 (:64-71; depthwise convolutions as grouped fp32 convolutions, ReLU6)."""
 import torch
 
 from .weights import load_guide_checkpoint, synthetic_guide
@@ -67,7 +67,8 @@ class GuideModel:
 
     def forward(self, x):
         f = self.encode_image(x)                  # CLIP: wrap_clip_forward's `fc(encode_image(x))` (model_utils.py:14-26)
-        w, b = self._sd["fc.weight"].to(f.device), self._sd["fc.bias"].to(f.device)
+        head = "classifier" if "classifier.weight" in self._sd else "fc"          # timm mobilenetv2: model.classifier (model_utils.py:69)
+        w, b = self._sd[head + ".weight"].to(f.device), self._sd[head + ".bias"].to(f.device)
         return torch.nn.functional.linear(f, w, b)   # classifier head: not on the expansion hot path
 
     __call__ = forward

@@ -244,10 +244,47 @@ def synthetic_guide_vit(cfg: EngineConfig, seed=0, num_classes=100):
     return b.sd
 
 
+def synthetic_guide_mbv2(cfg: EngineConfig, seed=0, num_classes=100):
+    """timm mobilenetv2_100 state dict: conv_stem / bn1, blocks.<stage>.<block>.{conv_dw, bn1, conv_pw, bn2} (stage 0, depthwise-separable)
+    or {conv_pw, bn1, conv_dw, bn2, conv_pwl, bn3} (inverted residual), conv_head / bn2, classifier."""
+    g = cfg.guide
+    b = _Builder("guide.", seed)
+
+    def dw(name, c):
+        b.sd[name + ".weight"] = _randn("guide." + name + ".w", (c, 1, 3, 3), 1.0 / 3.0, seed)
+
+    b.conv("conv_stem", g.mb_stem, 3, 3, bias=False)
+    b.bn("bn1", g.mb_stem)
+    inp = g.mb_stem
+    for s, (out, rep) in enumerate(zip(g.mb_channels, g.mb_repeats)):
+        for bi in range(rep):
+            p = "blocks.%d.%d" % (s, bi)
+            if s == 0:
+                dw(p + ".conv_dw", inp)
+                b.bn(p + ".bn1", inp)
+                b.conv(p + ".conv_pw", out, inp, 1, bias=False)
+                b.bn(p + ".bn2", out)
+            else:
+                mid = inp * g.mb_expand
+                b.conv(p + ".conv_pw", mid, inp, 1, bias=False)
+                b.bn(p + ".bn1", mid)
+                dw(p + ".conv_dw", mid)
+                b.bn(p + ".bn2", mid)
+                b.conv(p + ".conv_pwl", out, mid, 1, bias=False)
+                b.bn(p + ".bn3", out)
+            inp = out
+    b.conv("conv_head", g.mb_head, inp, 1, bias=False)
+    b.bn("bn2", g.mb_head)
+    b.linear("classifier", num_classes, g.mb_head)
+    return b.sd
+
+
 def synthetic_guide(cfg: EngineConfig, seed=0, num_classes=100):
     g = cfg.guide
     if g.kind == "vit":
         return synthetic_guide_vit(cfg, seed, num_classes)
+    if g.kind == "mbv2":
+        return synthetic_guide_mbv2(cfg, seed, num_classes)
     b = _Builder("guide.", seed)
     b.conv("conv1", g.stem_channels, 3, 7, bias=False)
     b.bn("bn1", g.stem_channels)

@@ -71,8 +71,11 @@ typedef struct dd_config {
   int text_act;         /* hidden_act: 0 quick_gelu (SD-1.x), 1 gelu */
   float text_eps;       /* layer_norm_eps (0: 1e-5) */
   /* guide model family: 0 = timm Bottleneck ResNets (resnet50 / resnext50_32x4d / wide_resnet50_2, exact fp32), 1 = the image tower of
-   * an open_clip ViT (open_clip_vit_b32, model_utils.py:80-87; bf16 MFMA): width, depth and MLP size come from the state dict */
+   * an open_clip ViT (open_clip_vit_b32, model_utils.py:80-87; bf16 MFMA): width, depth and MLP size come from the state dict,
+   * 2 = timm mobilenetv2_100 (model_utils.py:64-71, exact fp32): guide_stages stages of guide_blocks[s] blocks, the first of stride
+   * guide_strides[s]; channel counts, expansion and depthwise groups come from the weight shapes */
   int guide_kind;
+  int guide_strides[DD_MAX_LEVELS];
   int guide_vit_heads, guide_vit_patch;
   int guide_vit_act;    /* 0 quick_gelu, 1 gelu (open_clip 'ViT-B-32': gelu) */
   int guide_feature_dim; /* D of encode_image: 2048 (ResNets) / 512 (ViT-B/32 projection) */

@@ -331,6 +331,29 @@ class GuideOracle:
         return torch.flatten(f, 1)
 
 
+class GuideOracleMBV2(GuideOracle):
+    """timm mobilenetv2_100 forward_features (+ the pooling of model_utils.py:29-41), restated from the published timm definition."""
+
+    def forward_features(self, x):
+        g, sd = self.cfg.guide, self.sd
+        r6 = lambda t: F.relu6(t)
+        x = r6(self._bn(F.conv2d(x, sd["conv_stem.weight"], None, stride=2, padding=1), "bn1"))
+        for s, rep in enumerate(g.mb_repeats):
+            for bi in range(rep):
+                p = "blocks.%d.%d" % (s, bi)
+                stride = g.mb_strides[s] if bi == 0 else 1
+                inp = x
+                if (p + ".conv_pwl.weight") in sd:
+                    o = r6(self._bn(F.conv2d(x, sd[p + ".conv_pw.weight"]), p + ".bn1"))
+                    o = r6(self._bn(F.conv2d(o, sd[p + ".conv_dw.weight"], stride=stride, padding=1, groups=o.shape[1]), p + ".bn2"))
+                    o = self._bn(F.conv2d(o, sd[p + ".conv_pwl.weight"]), p + ".bn3")
+                else:
+                    o = r6(self._bn(F.conv2d(x, sd[p + ".conv_dw.weight"], stride=stride, padding=1, groups=x.shape[1]), p + ".bn1"))
+                    o = self._bn(F.conv2d(o, sd[p + ".conv_pw.weight"]), p + ".bn2")
+                x = o + inp if (stride == 1 and o.shape[1] == inp.shape[1]) else o
+        return r6(self._bn(F.conv2d(x, sd["conv_head.weight"]), "bn2"))
+
+
 class GuideOracleViT:
     """open_clip VisionTransformer.forward (image tower of 'ViT-B-32'; `model.encode_image` of the CLIP guide, model_utils.py:80-87),
     restated from the published open_clip definition (open_clip is not installed: unpinned like the other third-party modules):
@@ -511,5 +534,5 @@ def expand_one(args, cfg, models, image_latents, noise, e, b, prompt_embeds, neg
 
 
 def build_models(cfg, weights):
-    guide = (GuideOracleViT if cfg.guide.kind == "vit" else GuideOracle)(cfg, weights["guide"])
+    guide = {"vit": GuideOracleViT, "mbv2": GuideOracleMBV2}.get(cfg.guide.kind, GuideOracle)(cfg, weights["guide"])
     return (UNetOracle(cfg, weights["unet"]), VAEOracle(cfg, weights["vae"]), guide, DDIMSchedulerOracle(cfg))

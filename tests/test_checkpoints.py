@@ -116,7 +116,17 @@ def test_guide_checkpoint_round_trip(tmp_path, arch):
     m = create_model(arch, num_classes=7, weight_path=path)
     assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
     with pytest.raises(NotImplementedError):
-        create_model("mobilenetv2")
+        create_model("efficientnet_b0")          # not one of the reference's five architectures (model_utils.py:47-87)
+
+
+@pytest.mark.parametrize("arch,key,shape,dim", [("mobilenetv2", "blocks.1.0.conv_dw.weight", (96, 1, 3, 3), 1280),
+                                                ("open_clip_vit_b32", "visual.transformer.resblocks.11.attn.in_proj_weight", (2304, 768), 512)])
+def test_other_guide_families_shapes(arch, key, shape, dim):
+    """timm mobilenetv2_100 (model_utils.py:64-71) and the open_clip ViT-B/32 image tower (:80-87): state-dict key names / shapes."""
+    from distdiff_amd.config import guide_config
+    from distdiff_amd.model_utils import create_model
+    m = create_model(arch, num_classes=3)
+    assert tuple(m.state_dict()[key].shape) == shape and guide_config(arch).feature_dim == dim
 
 
 def test_dataset_listings(tmp_path):

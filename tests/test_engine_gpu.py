@@ -361,3 +361,34 @@ def test_packed_weights_export_import(hip_lib, fx):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     a.close(); b.close()
+
+
+def test_graph_replay_of_the_plain_step_is_bitwise_identical(hip_lib, fx):
+    """DD_GRAPH=1: the plain denoise step (UNet forward + CFG + DDIM, ~700 launches) is captured into a hipGraph on its second
+    sighting and replayed afterwards; results are bitwise those of the plain launches (off by default: no gain measured)."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from distdiff_amd.config import tiny_config\n"
+        "from distdiff_amd.engine import Engine\n"
+        "from distdiff_amd.scheduler import DDIMSchedule\n"
+        "from distdiff_amd.weights import synthetic_weights\n"
+        "cfg = tiny_config(max_batch=2)\n"
+        "eng = Engine(cfg, synthetic_weights(cfg, seed=0, num_classes=5), enable_grad=False, max_guidance_period=1)\n"
+        "s = DDIMSchedule(cfg.scheduler); ts = s.set_timesteps(10)\n"
+        "eng.set_schedule(ts, s.alphas_cumprod, s.final_alpha_cumprod)\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "eng.set_prompt(torch.randn(4, cfg.text_len, cfg.unet.cross_attention_dim, generator=g).cuda())\n"
+        "lat = torch.randn(2, 4, cfg.latent_size, cfg.latent_size, generator=g); nz = torch.randn(lat.shape, generator=g)\n"
+        "outs = [eng.expand(lat, nz, None, None, torch.zeros(2, dtype=torch.int64), 0, None, 0, 0)[0].cpu() for _ in range(4)]\n"
+        "assert all(torch.equal(outs[0], o) for o in outs[1:])\n"
+        "print('SUM %%.6f' %% float(outs[0].double().abs().sum()))\n" % os.path.join(os.path.dirname(__file__), ".."))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, DD_GRAPH=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = [l for l in r.stdout.splitlines() if l.startswith("SUM")][0]
+    assert res["0"] == res["1"], res

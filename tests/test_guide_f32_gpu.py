@@ -90,11 +90,11 @@ def _engine(cfg, w, B):
     return eng
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_grouped", "resnet50", "resnext50", "wideresnet50"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_grouped", "tiny_mbv2", "resnet50", "resnext50", "wideresnet50", "mobilenetv2"])
 def test_guide_forward_and_vjp_vs_oracle(hip_lib, which):
     """encode_image and its input-gradient, through the production C ABI, at the tiny widths and at the real widths of the three
-    Bottleneck guides of the reference at 224x224: resnet50 (64-256-512-1024-2048), resnext50 = resnext50_32x4d
-    (32 groups in every 3x3) and wideresnet50 = wide_resnet50_2 (model_utils.py:47-79)."""
+    fp32 guides of the reference at 224x224: resnet50 (64-256-512-1024-2048), resnext50 = resnext50_32x4d (32 groups in
+    every 3x3), wideresnet50 = wide_resnet50_2 and mobilenetv2 = mobilenetv2_100 (depthwise 3x3, ReLU6) (model_utils.py:47-79)."""
     from distdiff_amd.config import GuideConfig, guide_config, sd15_config, tiny_config
     from distdiff_amd.weights import synthetic_weights
     from oracle import sd_oracle as O
@@ -104,12 +104,16 @@ def test_guide_forward_and_vjp_vs_oracle(hip_lib, which):
     elif which == "tiny_grouped":
         cfg = tiny_config(max_batch=B)
         cfg.guide = GuideConfig(stem_channels=16, planes=(16, 32, 32, 64), blocks=(1, 2, 1, 1), input_size=56, cardinality=4, base_width=16)
+    elif which == "tiny_mbv2":
+        cfg = tiny_config(max_batch=B)
+        cfg.guide = GuideConfig(kind="mbv2", input_size=64, mb_stem=16, mb_channels=(16, 16, 32), mb_repeats=(1, 2, 2), mb_strides=(1, 2, 2),
+                                mb_expand=2, mb_head=64)
     else:
         cfg = sd15_config(latent_size=8, max_batch=B)     # SD widths at an 8x8 latent keep the UNet/VAE slabs small; the guide is full size
         cfg.guide = guide_config(which)
     w = synthetic_weights(cfg, seed=0, num_classes=5)
     eng = _engine(cfg, w, B)
-    guide = O.GuideOracle(cfg, w["guide"])
+    guide = O.build_models(cfg, w)[2]
     S = cfg.guide.input_size
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, 3, S, S, generator=g) * 0.5
@@ -118,7 +122,9 @@ def test_guide_forward_and_vjp_vs_oracle(hip_lib, which):
     f_ref = guide.encode_image(xr)
     (g_ref,) = torch.autograd.grad(f_ref, xr, gf)
     assert rel(eng.guide_encode(x), f_ref.detach()) < 1e-4
-    assert rel(eng.guide_vjp(x, gf), g_ref) < 2e-3
+    # fp32 vs fp32: summation order only, plus a handful of activations within fp32 rounding of a ReLU / ReLU6 kink (measured 4e-7
+    # on the ResNets, 2.7e-3 on the 53-layer two-sided-mask MobileNetV2)
+    assert rel(eng.guide_vjp(x, gf), g_ref) < (5e-3 if cfg.guide.kind == "mbv2" else 2e-3)
     eng.close()
 
 
