@@ -113,8 +113,10 @@ def recorded_traffic(B, config):
 
     PMC collection needs rocprofv3 around the whole process, so it cannot run inside the timed region; the
     number is only attached when the committed passes were taken on this exact workload (same batch)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_b%d_pmc_traffic.json" % B)
-    if config != "sd15" or not os.path.exists(path):
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((p for p in (os.path.join(root, "r%02d_b%d_pmc_traffic.json" % (r, B)) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)) if os.path.exists(p)),
+                None)
+    if config != "sd15" or path is None:
         return {}
     with open(path) as f:
         t = json.load(f)
