@@ -48,7 +48,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // FM: 1 = fast staging path only (Cin % 64 == 0, no fused upsample / dilation, <= 32 taps: buffer loads with scalar tap offsets),
 //     0 = general path only (per-lane address arithmetic, global_load_lds).  FE: batched epilogue compiled in.
-template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
+// ST: the CF_STATS epilogue is compiled in (its own instantiation: the code of the plain kernels -- above all the register allocation
+// of their K loop -- stays exactly what it was without it).
+template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm_big_kernel(ConvGemmParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int NW = WM * WN;   // 8 waves (one workgroup per CU) or 4 waves (two workgroups per CU, <= 256 VGPRs each)
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
         }
       }
       float s1[TN][4], s2[TN][4];
-      if (fl & CF_STATS) {
+      if (ST && (fl & CF_STATS)) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
             v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
           }
           if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-          if (fl & CF_STATS) {
+          if (ST && (fl & CF_STATS)) {
             t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
             t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
             t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
         }
         if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y, s1[TN - 1], s2[TN - 1]);
       }
-      if (fl & CF_STATS) emit_stats(s1, s2, m0 + wm * (TM * 16), wb);
+      if (ST && (fl & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), wb);
       return;
     }
     if constexpr ((TN & 1) == 0) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     }
     }  // FE
     float s1[TN][4], s2[TN][4];
-    if (p.flags & CF_STATS) {
+    if (ST && (p.flags & CF_STATS)) {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -470,14 +472,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = acc[jn][i][r];
           Epi::apply(p, bias, m, nb, h, h, 0);     // leaves the stored values (before the bf16 rounding) in h
-          if (p.flags & CF_STATS) {
+          if (ST && (p.flags & CF_STATS)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s1[jn][r] += h[r]; s2[jn][r] = __builtin_fmaf(h[r], h[r], s2[jn][r]); }
           }
         }
       }
     }
-    if (p.flags & CF_STATS) emit_stats(s1, s2, m0 + wm * (TM * 16), n0 + wn * (TN * 16));
+    if (ST && (p.flags & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), n0 + wn * (TN * 16));
   };
 
   // ---- pipeline: NS = 3 LDS stages, software-pipelined through registers.  K-step s reads its two 32-wide halves as
@@ -554,18 +556,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   }
 }
 
-template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
-hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
+template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
+hipError_t run_big_fe3(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int lds = NS * (BM + BN) * 128 + 256;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets)
   static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int W = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit;
   constexpr int WGS = 256 * ((WM * WN == 4) ? 2 : 1);   // persistent: one 8-wave or two 4-wave workgroups per CU
   int G = W < WGS ? (W + 7) / 8 * 8 : WGS;
-  hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM>), dim3(G), dim3(WM * WN * 64), lds, stream, p);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM, ST>), dim3(G), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
+}
+template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
+hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
+  return (p.flags & CF_STATS) ? run_big_fe3<WM, WN, TM, TN, NS, FE, FM, true>(p, stream) : run_big_fe3<WM, WN, TM, TN, NS, FE, FM, false>(p, stream);
 }
 
 template <int WM, int WN, int TM, int TN, int NS, bool FE>

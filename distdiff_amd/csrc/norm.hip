@@ -160,39 +160,55 @@ __global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(GroupNormParams
 }
 
 // Pass 1+2 when the producing convolutions emitted per-(64-row block, channel) partials (mean, M2 over 64 rows; CF_STATS of the
-// implicit-GEMM epilogue): one wave per (b, g) merges the (HW / 64) x (C / G) partials of its group, no pass over the tensor.
+// implicit-GEMM epilogue): one 256-thread workgroup per (b, g) merges the (HW / 64) x (C / G) partials of its group, no pass over the
+// tensor.  All partials have the same count, so the merge is mean = avg(mean_p), M2 = sum(M2_p) + 64 * sum((mean_p - mean)^2), with
+// every thread's partials held in registers between the two reductions; fixed-order wave + LDS sums (bitwise reproducible).
+__device__ __forceinline__ float gn_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ __launch_bounds__(GN_THREADS) void gn_finalize_chan_kernel(GroupNormParams p) {
-  const int lane = threadIdx.x & 63;
-  const int bg = blockIdx.x * (GN_THREADS / 64) + (threadIdx.x >> 6);
-  if (bg >= p.B * p.G) return;
+  __shared__ float red[4];
+  const int bg = blockIdx.x;
   const int b = bg / p.G, g = bg % p.G;
   const int cpg = p.C / p.G, nb = p.HW >> 6, P = nb * cpg;
-  float n = 0.f, mean = 0.f, M2 = 0.f;
-  for (int e = lane; e < P; e += 64) {
-    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
-    const float2 in = *(const float2*)(p.chan_part + (((size_t)b * nb + rb) * p.part_ld + c) * 2);
-    const float nn = n + 64.f, d = in.x - mean;
-    mean += d * (64.f / nn);
-    M2 += in.y + d * d * (n * 64.f / nn);
-    n = nn;
-  }
+  constexpr int MAXP = 12;                       // partials per thread kept in registers (P <= 3072); beyond that they are re-read
+  float pm[MAXP], pM[MAXP];
+  float s = 0.f;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float nb2 = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), M2b = __shfl_xor(M2, o, 64);
-    const float nn = n + nb2;
-    if (nn > 0.f) {
-      const float lo_n = (lane & o) ? nb2 : n, hi_n = (lane & o) ? n : nb2;
-      const float lo_m = (lane & o) ? mb : mean, hi_m = (lane & o) ? mean : mb;
-      const float lo_M = (lane & o) ? M2b : M2, hi_M = (lane & o) ? M2 : M2b;
-      const float d = hi_m - lo_m;
-      mean = lo_m + d * (hi_n / nn);
-      M2 = lo_M + hi_M + d * d * (lo_n * hi_n / nn);
-      n = nn;
+  for (int i = 0; i < MAXP; ++i) {
+    const int e = threadIdx.x + i * GN_THREADS;
+    pm[i] = 0.f; pM[i] = 0.f;
+    if (e < P) {
+      const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+      const float2 in = *(const float2*)(p.chan_part + (((size_t)b * nb + rb) * p.part_ld + c) * 2);
+      pm[i] = in.x; pM[i] = in.y; s += in.x;
     }
   }
-  if (lane == 0) {
+  for (int e = threadIdx.x + MAXP * GN_THREADS; e < P; e += GN_THREADS) {
+    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+    s += p.chan_part[(((size_t)b * nb + rb) * p.part_ld + c) * 2];
+  }
+  const float mean = gn_block_sum(s, red) / (float)P;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int e = threadIdx.x + i * GN_THREADS;
+    if (e < P) { const float d = pm[i] - mean; q += pM[i] + 64.f * d * d; }
+  }
+  for (int e = threadIdx.x + MAXP * GN_THREADS; e < P; e += GN_THREADS) {
+    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+    const float2 in = *(const float2*)(p.chan_part + (((size_t)b * nb + rb) * p.part_ld + c) * 2);
+    const float d = in.x - mean;
+    q += in.y + 64.f * d * d;
+  }
+  const float M2 = gn_block_sum(q, red);
+  if (threadIdx.x == 0) {
     p.stats[((size_t)b * p.G + g) * 2] = mean;
-    p.stats[((size_t)b * p.G + g) * 2 + 1] = rsqrtf(fmaxf(M2, 0.f) / n + p.eps);
+    p.stats[((size_t)b * p.G + g) * 2 + 1] = rsqrtf(fmaxf(M2, 0.f) / (64.f * (float)P) + p.eps);
   }
 }
 
@@ -398,7 +414,7 @@ static hipError_t gn_launch(const GroupNormParams& p, hipStream_t stream) {
   float* fin = p.scratch + (size_t)p.B * GN_MAX_SPLIT * p.G * 3;   // [B][G][2] finalize output of the backward sums
   if (!BWD && p.chan_part) {
     if (p.HW & 63) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_finalize_chan_kernel, dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(gn_finalize_chan_kernel, dim3(p.B * p.G), dim3(GN_THREADS), 0, stream, p);
   } else {
     hipLaunchKernelGGL((gn_partial_kernel<BWD>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
     hipLaunchKernelGGL((gn_finalize_kernel<BWD>), dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p, S, fin);
