@@ -169,7 +169,7 @@ def main():
     def make_engine(c, w, layout):
         return Engine(c, w, enable_grad=guided, max_guidance_period=stash, device=str(dev), layout=layout)
 
-    if distributed and world > 1:
+    if distributed and (world > 1 or os.environ.get("DD_FORCE_BROADCAST")):     # the env switch rehearses the RCCL start-up path on 1 GPU
         # rank 0 synthesises + packs the weights once; the PACKED device buffers reach the other ranks in one RCCL broadcast over xGMI
         def load():
             nonlocal weights

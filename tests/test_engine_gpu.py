@@ -285,7 +285,7 @@ def test_full_size_sd15_properties(hip_lib):
     assert img.shape == (1, 3, 512, 512) and float(img.min()) >= 0 and float(img.max()) <= 1
     # VJP linearity at full size
     gg = torch.randn(2, 4, 64, 64, generator=g)
-    # linear in the cotangent up to the bf16 rounding-pattern noise of the reverse pass (tools/lin_bisect.py: MFMA accumulation is
+    # linear in the cotangent up to the bf16 rounding-pattern noise of the reverse pass (measured by bisecting the reverse program op by op: MFMA accumulation is
     # homogeneous only to ~1e-7, which re-draws the bf16 roundings downstream; the two runs then differ like two noise draws)
     v1, v2 = eng.unet_vjp(z, 30, gg), eng.unet_vjp(z, 30, -4.0 * gg)
     assert rel(v2, -4.0 * v1) < 0.03
