@@ -26,10 +26,23 @@ class UNetConfig:
     norm_eps: float = 1e-5
     freq_shift: float = 0.0
     flip_sin_to_cos: bool = True
+    # SDXL-style UNets (BASELINE.json configs[4]; unet/config.json `transformer_layers_per_block`, per-level `attention_head_dim`,
+    # `addition_embed_type: text_time`): empty / 0 = the SD-1.x structure (one transformer block per attention, num_heads everywhere,
+    # no additional conditioning)
+    transformer_depth: Tuple[int, ...] = ()
+    level_heads: Tuple[int, ...] = ()
+    add_time_dim: int = 0              # addition_time_embed_dim (256): sinusoid width of each of the 6 time ids
+    add_text_dim: int = 0              # pooled text embedding width (1280); add_embedding input = add_text_dim + 6 * add_time_dim
 
     @property
     def time_embed_dim(self):
         return self.block_out_channels[0] * 4
+
+    def depth(self, level):
+        return self.transformer_depth[level] if self.transformer_depth else 1
+
+    def heads(self, level):
+        return self.level_heads[level] if self.level_heads else self.num_heads
 
 
 @dataclass
@@ -148,6 +161,27 @@ def sd15_config(latent_size=64, max_batch=1):
     return EngineConfig(latent_size=latent_size, max_batch=max_batch)
 
 
+def sdxl_config(latent_size=128, max_batch=1):
+    """Stable-Diffusion-XL base UNet (BASELINE.json configs[4]: 1024x1024 -> 128x128 latents) with the SD-family AutoencoderKL
+    (scaling_factor 0.13025).  The reference cannot run this model (single text encoder, no added_cond_kwargs: SURVEY.md 8d C5)."""
+    cfg = EngineConfig(latent_size=latent_size, max_batch=max_batch)
+    cfg.unet = UNetConfig(block_out_channels=(320, 640, 1280), layers_per_block=2, down_attn=(False, True, True), up_attn=(True, True, False),
+                          num_heads=10, cross_attention_dim=2048, transformer_depth=(1, 2, 10), level_heads=(5, 10, 20),
+                          add_time_dim=256, add_text_dim=1280)
+    cfg.vae.scaling_factor = 0.13025
+    return cfg
+
+
+def tiny_sdxl_config(latent_size=16, max_batch=2):
+    """The SDXL structure at test size: 3 levels, attention on the last two, transformer depths (1, 2, 3), per-level head counts,
+    text_time additional conditioning."""
+    cfg = tiny_config(latent_size, max_batch)
+    cfg.unet = UNetConfig(block_out_channels=(64, 128, 128), layers_per_block=1, down_attn=(False, True, True), up_attn=(True, True, False),
+                          num_heads=2, cross_attention_dim=64, norm_num_groups=8, transformer_depth=(1, 2, 3), level_heads=(2, 2, 4),
+                          add_time_dim=8, add_text_dim=24)
+    return cfg
+
+
 def tiny_config(latent_size=16, max_batch=2):
     """Small architecture with the same topology (all block types, up/down sampling, cross attention,
     GEGLU, VAE attention, bottleneck guide) used by the parity tests, golden vectors and smoke()."""
@@ -183,6 +217,17 @@ def from_model_dir(path, latent_size=64, max_batch=1):
         if "down_block_types" in u:
             cfg.unet.down_attn = tuple("CrossAttn" in t for t in u["down_block_types"])
             cfg.unet.up_attn = tuple("CrossAttn" in t for t in u["up_block_types"])
+        nl = len(cfg.unet.block_out_channels)
+        if isinstance(u.get("attention_head_dim"), (list, tuple)):          # SDXL: per-level head COUNTS
+            cfg.unet.level_heads = tuple(u["attention_head_dim"])
+            cfg.unet.num_heads = cfg.unet.level_heads[-1]
+        tl = u.get("transformer_layers_per_block", 1)
+        cfg.unet.transformer_depth = tuple(tl) if isinstance(tl, (list, tuple)) else ((tl,) * nl if tl != 1 else ())
+        if u.get("addition_embed_type") == "text_time":
+            cfg.unet.add_time_dim = u.get("addition_time_embed_dim", 256)
+            cfg.unet.add_text_dim = u.get("projection_class_embeddings_input_dim", 2816) - 6 * cfg.unet.add_time_dim
+        elif u.get("addition_embed_type"):
+            raise NotImplementedError("unet addition_embed_type=%r is not built" % u["addition_embed_type"])
     v = _load("vae/config.json")
     if v:
         cfg.vae.block_out_channels = tuple(v.get("block_out_channels", cfg.vae.block_out_channels))

@@ -487,6 +487,23 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, const f
   s = wave_sum(s);
   if (lane == 0) y[(size_t)m * N + n] = s + (b ? b[n] : 0.f);
 }
+__global__ void sinusoid_kernel(const float* x, float* out, int n, int dim, int ld, int off, int flip) {
+  const int half = dim / 2;
+  GRID_STRIDE(i, (size_t)n * half) {
+    const int j = (int)(i % half), r = (int)(i / half);
+    const float a = x[r] * __expf(-logf(10000.f) * (float)j / (float)half);
+    const float sn = sinf(a), cs = cosf(a);
+    float* o = out + (size_t)r * ld + off;
+    if (flip) { o[j] = cs; o[half + j] = sn; } else { o[j] = sn; o[half + j] = cs; }
+  }
+}
+__global__ void add_outer_kernel(const float* a, const float* v, float* out, int ns, int nb, int cols) {
+  GRID_STRIDE(i, (size_t)ns * nb * cols) {
+    const int c = (int)(i % cols);
+    const size_t row = i / cols;
+    out[i] = a[(row / nb) * cols + c] + v[(row % nb) * cols + c];
+  }
+}
 __global__ void add_rowvec_kernel(float* y, const float* v, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) y[i] += v[i % cols]; }
 __global__ void scale_rows_kernel(float* x, const float* s, int rows, int cols) { GRID_STRIDE(i, (size_t)rows * cols) x[i] *= s[0]; }
 
@@ -697,6 +714,12 @@ hipError_t launch_sub_scaled(const float* a, const float* g, float* out, size_t 
 }
 hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) { LAUNCH(f32_to_bf16_kernel, n, src, dst, n); }
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s) { LAUNCH(fill_kernel, n, dst, v, n); }
+hipError_t launch_sinusoid_f32(const float* x, float* out, int n, int dim, int ld, int off, int flip, hipStream_t s) {
+  LAUNCH(sinusoid_kernel, (size_t)n * (dim / 2), x, out, n, dim, ld, off, flip);
+}
+hipError_t launch_add_outer_f32(const float* a, const float* v, float* out, int ns, int nb, int cols, hipStream_t s) {
+  LAUNCH(add_outer_kernel, (size_t)ns * nb * cols, a, v, out, ns, nb, cols);
+}
 hipError_t launch_add_rowvec_f32(float* y, const float* v, int rows, int cols, hipStream_t s) {
   LAUNCH(add_rowvec_kernel, (size_t)rows * cols, y, v, rows, cols);
 }

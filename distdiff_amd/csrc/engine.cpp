@@ -64,6 +64,7 @@ struct ConvW {
   bf16_t* w_bwd = nullptr; int* tap_bwd = nullptr;
   float* bias = nullptr;       // [Cout] (packed order for GEGLU) or null
   float* bias_table = nullptr; // [n_steps][Cout] per-timestep effective bias (resnet conv1 + time_emb_proj)
+  float* bias_table_img = nullptr;   // SDXL text_time conditioning: [n_steps][2B][Cout], filled by dd_set_added_cond
   // fp32 copies kept for the time-embedding tables
   float* temb_w = nullptr; float* temb_b = nullptr;
 };
@@ -174,6 +175,7 @@ struct Ctx {  // per-call execution context
   double* flops = nullptr;
   Profiler* prof = nullptr;
   bool stash = true;     // false on plain (no-VJP) steps: skip stores that only the reverse program reads
+  int img_bias = 0;      // > 0: the time-embedding bias is per image (SDXL added conditioning): number of images (2B) of the tables
 };
 
 inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
@@ -207,6 +209,10 @@ struct dd_engine {
   bf16_t* ctx_bf16 = nullptr;                         // [2B*text_len, cross_dim]
   std::vector<ConvW*> temb_convs;                     // resnet conv1's with time_emb_proj
   float* temb_w1 = nullptr; float* temb_b1 = nullptr; float* temb_w2 = nullptr; float* temb_b2 = nullptr;
+  // SDXL text_time conditioning
+  float* add_w1 = nullptr; float* add_b1 = nullptr; float* add_w2 = nullptr; float* add_b2 = nullptr;
+  float* d_emb = nullptr;          // [n_steps][TE] time_embedding(t) of the current schedule
+  bool added_cond_set = false;
 
   // schedule
   std::vector<int> timesteps;
@@ -731,6 +737,31 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
           if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
         }
         p.flags = flags;
+        if (op.use_table && c.img_bias > 0 && w->bias_table_img) {
+          // SDXL text_time conditioning: the time-embedding bias differs per image -> one launch per image of the batch (B x H x W
+          // rows each; at 128x128 / 64x64 / 32x32 latents an image still fills the chip), each with its own row of the bias table
+          if (x.B != c.img_bias || op.stride != 1 || op.up) throw std::runtime_error("per-image bias: unexpected conv geometry");
+          const size_t xrows = (size_t)x.H * x.W, yrows = (size_t)y.H * y.W;
+          ConvGemmParams q = p;
+          q.B = 1; q.M = (int)yrows;
+          bool emit = false;
+          if (op.part) {
+            q.stats = (float*)(c.act + op.part_off); q.stats_ld = op.part_ld;
+            emit = !(yrows & 63) && conv_gemm_can_emit_stats(q, c.partial_cap);
+            if (emit) q.flags |= CF_STATS; else q.stats = nullptr;
+            P.emitted[i] = emit ? 1 : 0;
+          }
+          for (int bi = 0; bi < x.B; ++bi) {
+            ConvGemmParams r = q;
+            r.x = p.x + bi * xrows * x.ld;
+            r.y = (char*)p.y + bi * yrows * y.ld * 2;
+            r.bias = w->bias_table_img + ((size_t)c.step_index * c.img_bias + bi) * w->Cout;
+            if (emit) r.stats = q.stats + (size_t)bi * (yrows / 64) * op.part_ld * 2;
+            HIPCHK(launch_conv_gemm(r, c.partial_cap, c.s));
+          }
+          if (c.flops) *c.flops += op.flops;
+          break;
+        }
         if (op.part) {
           p.stats = (float*)(c.act + op.part_off); p.stats_ld = op.part_ld;
           const bool emit = conv_gemm_can_emit_stats(p, c.partial_cap);
@@ -986,34 +1017,40 @@ int build_resnet(Builder& b, const std::string& model, const std::string& p, int
   return b.conv(h, c2, 1, 0, sc);
 }
 
-int build_transformer(Builder& b, const std::string& p, int x, int heads, int G) {
+// diffusers Transformer2DModel: GroupNorm -> proj_in -> `depth` BasicTransformerBlocks -> proj_out + residual.  proj_in / proj_out are
+// 1x1 convolutions (SD-1.x) or nn.Linear (SDXL, use_linear_projection): both are [C, C] GEMMs on NHWC rows here.
+int build_transformer(Builder& b, const std::string& p, int x, int heads, int G, int depth) {
   dd_engine* E = b.E;
   Program& P = b.P;
   const std::string m = "unet";
   const int C = P.t[x].C, HW = P.t[x].H * P.t[x].W;
   int h = b.gn(x, make_norm(E, m, p + ".norm"), G, 1e-6f, 0);
   h = b.conv(h, make_conv(E, m, p + ".proj_in", 0));
-  const std::string t = p + ".transformer_blocks.0";
-  // self attention (fused QKV projection, no bias)
-  int n = b.ln(h, make_norm(E, m, t + ".norm1"), 1e-5f);
-  int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false));
-  int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
-  int a = b.attn(q, k, v, heads, HW, HW, -1);
-  h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
-  // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
-  n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
-  int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false));
-  dd_engine::CrossSlot slot;
-  slot.wk = make_conv(E, m, t + ".attn2.to_k", 0, false, false);
-  slot.wv = make_conv(E, m, t + ".attn2.to_v", 0, false, false);
-  slot.C = C;
-  E->cross_slots.push_back(slot);
-  a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1);
-  h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
-  // GEGLU feed-forward
-  n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);
-  int ff = b.conv(n, make_conv(E, m, t + ".ff.net.0.proj", 0, true));
-  h = b.conv(ff, make_conv(E, m, t + ".ff.net.2", 0), 1, 0, h);
+  char tb[32];
+  for (int d = 0; d < depth; ++d) {
+    snprintf(tb, sizeof tb, ".transformer_blocks.%d", d);
+    const std::string t = p + tb;
+    // self attention (fused QKV projection, no bias)
+    int n = b.ln(h, make_norm(E, m, t + ".norm1"), 1e-5f);
+    int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false));
+    int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+    int a = b.attn(q, k, v, heads, HW, HW, -1);
+    h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
+    // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
+    n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
+    int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false));
+    dd_engine::CrossSlot slot;
+    slot.wk = make_conv(E, m, t + ".attn2.to_k", 0, false, false);
+    slot.wv = make_conv(E, m, t + ".attn2.to_v", 0, false, false);
+    slot.C = C;
+    E->cross_slots.push_back(slot);
+    a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1);
+    h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
+    // GEGLU feed-forward
+    n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);
+    int ff = b.conv(n, make_conv(E, m, t + ".ff.net.0.proj", 0, true));
+    h = b.conv(ff, make_conv(E, m, t + ".ff.net.2", 0), 1, 0, h);
+  }
   return b.conv(h, make_conv(E, m, p + ".proj_out", 0), 1, 0, x);
 }
 
@@ -1025,6 +1062,8 @@ void build_unet(dd_engine* E) {
   const int B2 = 2 * c.max_batch, L = c.latent_size, G = c.unet_groups, nl = c.unet_levels;
   const float eps = c.unet_eps;
   const std::string m = "unet";
+  auto heads_of = [&](int lev) { return c.unet_level_heads[lev] > 0 ? c.unet_level_heads[lev] : c.unet_num_heads; };
+  auto depth_of = [&](int lev) { return c.unet_transformer_depth[lev] > 0 ? c.unet_transformer_depth[lev] : 1; };
   E->unet_in = P.tensor(B2, L, L, c.unet_in_channels);
   int h = b.conv(E->unet_in, make_conv(E, m, "conv_in", 1));
   std::vector<int> skips{h};
@@ -1033,7 +1072,7 @@ void build_unet(dd_engine* E) {
     for (int j = 0; j < c.unet_layers_per_block; ++j) {
       snprintf(buf, sizeof buf, "down_blocks.%d.resnets.%d", i, j);
       h = build_resnet(b, m, buf, h, G, eps, true);
-      if (c.unet_down_attn[i]) { snprintf(buf, sizeof buf, "down_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, c.unet_num_heads, G); }
+      if (c.unet_down_attn[i]) { snprintf(buf, sizeof buf, "down_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, heads_of(i), G, depth_of(i)); }
       skips.push_back(h);
     }
     if (i < nl - 1) {
@@ -1043,14 +1082,14 @@ void build_unet(dd_engine* E) {
     }
   }
   h = build_resnet(b, m, "mid_block.resnets.0", h, G, eps, true);
-  h = build_transformer(b, "mid_block.attentions.0", h, c.unet_num_heads, G);
+  h = build_transformer(b, "mid_block.attentions.0", h, heads_of(nl - 1), G, depth_of(nl - 1));
   h = build_resnet(b, m, "mid_block.resnets.1", h, G, eps, true);
   for (int i = 0; i < nl; ++i) {
     for (int j = 0; j < c.unet_layers_per_block + 1; ++j) {
       h = b.concat(h, skips.back()); skips.pop_back();
       snprintf(buf, sizeof buf, "up_blocks.%d.resnets.%d", i, j);
       h = build_resnet(b, m, buf, h, G, eps, true);
-      if (c.unet_up_attn[i]) { snprintf(buf, sizeof buf, "up_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, c.unet_num_heads, G); }
+      if (c.unet_up_attn[i]) { snprintf(buf, sizeof buf, "up_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, heads_of(nl - 1 - i), G, depth_of(nl - 1 - i)); }
     }
     if (i < nl - 1) {
       snprintf(buf, sizeof buf, "up_blocks.%d.upsamplers.0.conv", i);
@@ -1361,6 +1400,10 @@ void unet_fwd(dd_engine* E, int k, const float* z, int step_index, hipStream_t s
   Ctx ctx = r.ctx(E->unet, E->inst[k].unet);
   ctx.step_index = step_index;
   ctx.stash = stash;
+  if (c.unet_add_time_dim > 0) {
+    if (!E->added_cond_set) throw std::runtime_error("this UNet has text_time additional conditioning: call dd_set_added_cond first");
+    ctx.img_bias = 2 * c.max_batch;
+  }
   const Tn& in = E->unet.t[E->unet_in];
   HIPCHK(launch_nchw_f32_to_nhwc_bf16(z, act_ptr(ctx, in), c.max_batch, c.unet_in_channels, c.latent_size, c.latent_size, in.ld, in.ld, 1,
                                       1.f, s));
@@ -1581,6 +1624,10 @@ int dd_finalize_weights(dd_engine* E) {
     };
     E->temb_w1 = up("time_embedding.linear_1.weight"); E->temb_b1 = up("time_embedding.linear_1.bias");
     E->temb_w2 = up("time_embedding.linear_2.weight"); E->temb_b2 = up("time_embedding.linear_2.bias");
+    if (c.unet_add_time_dim > 0) {
+      E->add_w1 = up("add_embedding.linear_1.weight"); E->add_b1 = up("add_embedding.linear_1.bias");
+      E->add_w2 = up("add_embedding.linear_2.weight"); E->add_b2 = up("add_embedding.linear_2.bias");
+    }
     E->raw.clear();
     // activation slabs
     const int P = c.enable_grad ? c.max_guidance_period : 1;
@@ -1675,6 +1722,8 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
     float* d_h1 = (float*)E->dmalloc((size_t)n * TE * 4, false);
     float* d_emb = (float*)E->dmalloc((size_t)n * TE * 4, false);
     E->sched_allocs.push_back(d_sin); E->sched_allocs.push_back(d_h1); E->sched_allocs.push_back(d_emb);
+    E->d_emb = d_emb;
+    E->added_cond_set = false;
     HIPCHK(launch_linear_f32(d_sin, E->temb_w1, E->temb_b1, d_h1, n, TE, C0, 0, nullptr));
     HIPCHK(launch_linear_f32(d_h1, E->temb_w2, E->temb_b2, d_emb, n, TE, TE, 1, nullptr));
     for (ConvW* cw : E->temb_convs) {
@@ -1682,6 +1731,10 @@ int dd_set_schedule(dd_engine* E, const int* timesteps, int n, const float* alph
       E->sched_allocs.push_back(cw->bias_table);
       HIPCHK(launch_linear_f32(d_emb, cw->temb_w, cw->temb_b, cw->bias_table, n, cw->Cout, TE, 1, nullptr));
       if (cw->bias) HIPCHK(launch_add_rowvec_f32(cw->bias_table, cw->bias, n, cw->Cout, nullptr));   // + conv1.bias
+      if (c.unet_add_time_dim > 0) {
+        cw->bias_table_img = (float*)E->dmalloc((size_t)n * 2 * c.max_batch * cw->Cout * 4, false);
+        E->sched_allocs.push_back(cw->bias_table_img);
+      }
     }
     HIPCHK(hipDeviceSynchronize());
   });
@@ -1721,6 +1774,40 @@ int dd_set_prompt(dd_engine* E, const float* embeds, int B, void* stream) {
         HIPCHK(launch_conv_gemm(p, E->partial_cap, s));
       }
     }
+  });
+}
+
+int dd_set_added_cond(dd_engine* E, const float* text_embeds, const float* time_ids, int B, void* stream) {
+  if (!E || !text_embeds || !time_ids) return DD_ERR_ARG;
+  DD_TRY(E, {
+    check_batch(E, B);
+    const dd_config& c = E->cfg;
+    if (c.unet_add_time_dim <= 0) throw std::runtime_error("this UNet has no additional conditioning (unet_add_time_dim == 0)");
+    if (!E->d_emb) throw std::runtime_error("dd_set_schedule first");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = 2 * B, n = (int)E->timesteps.size(), TE = c.unet_block_out_channels[0] * 4;
+    const int Dt = c.unet_add_text_dim, Ds = 6 * c.unet_add_time_dim, Din = Dt + Ds;
+    // scratch (setup path: plain allocations, freed at the end)
+    float* cat = nullptr; float* h1 = nullptr; float* aug = nullptr; float* X = nullptr;
+    HIPCHK(hipMalloc((void**)&cat, (size_t)nb * Din * 4)); HIPCHK(hipMalloc((void**)&h1, (size_t)nb * TE * 4));
+    HIPCHK(hipMalloc((void**)&aug, (size_t)nb * TE * 4)); HIPCHK(hipMalloc((void**)&X, (size_t)n * nb * TE * 4));
+    // cat[text_embeds, add_time_proj(time_ids).reshape(B, -1)]
+    HIPCHK(hipMemcpy2DAsync(cat, (size_t)Din * 4, text_embeds, (size_t)Dt * 4, (size_t)Dt * 4, nb, hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < 6; ++k) {
+      // time id k of every image -> columns [Dt + k*dim, Dt + (k+1)*dim): gather the k-th id with a strided copy first
+      HIPCHK(hipMemcpy2DAsync(h1, 4, time_ids + k, 6 * 4, 4, nb, hipMemcpyDeviceToDevice, s));
+      HIPCHK(launch_sinusoid_f32(h1, cat, nb, c.unet_add_time_dim, Din, Dt + k * c.unet_add_time_dim, 1, s));
+    }
+    HIPCHK(launch_linear_f32(cat, E->add_w1, E->add_b1, h1, nb, TE, Din, 0, s));
+    HIPCHK(launch_linear_f32(h1, E->add_w2, E->add_b2, aug, nb, TE, TE, 1, s));
+    HIPCHK(launch_add_outer_f32(E->d_emb, aug, X, n, nb, TE, s));                 // emb[step, image] = time_embedding(t) + aug_emb
+    for (ConvW* cw : E->temb_convs) {
+      HIPCHK(launch_linear_f32(X, cw->temb_w, cw->temb_b, cw->bias_table_img, n * nb, cw->Cout, TE, 1, s));
+      if (cw->bias) HIPCHK(launch_add_rowvec_f32(cw->bias_table_img, cw->bias, n * nb, cw->Cout, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    hipFree(cat); hipFree(h1); hipFree(aug); hipFree(X);
+    E->added_cond_set = true;
   });
 }
 

@@ -201,6 +201,10 @@ hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream
 // setup-time fp32 linear: y = act(x) W^T + b (time-embedding tables)
 hipError_t launch_linear_f32(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int silu_in, hipStream_t s);
 hipError_t launch_fill_f32(float* dst, float v, size_t n, hipStream_t s);
+// SDXL added conditioning (setup-time, fp32): sinusoidal embedding of n scalars (diffusers Timesteps: flip_sin_to_cos, shift 0) into
+// out[i*ld + off .. + dim); out[(s*nb + b), :] = a[s, :] + v[b, :]
+hipError_t launch_sinusoid_f32(const float* x, float* out, int n, int dim, int ld, int off, int flip, hipStream_t s);
+hipError_t launch_add_outer_f32(const float* a, const float* v, float* out, int ns, int nb, int cols, hipStream_t s);
 // y[r, c] += v[c]  (fp32 rows; setup-time: the per-timestep bias tables)
 hipError_t launch_add_rowvec_f32(float* y, const float* v, int rows, int cols, hipStream_t s);
 // (x/2+0.5).clamp(0,1)*255+0.5 -> uint8 HWC (output stage, generate_data.py:1227 + save_image quantisation)

@@ -32,6 +32,7 @@ class DDConfig(C.Structure):
         ("text_heads", C.c_int), ("text_act", C.c_int), ("text_eps", C.c_float),
         ("guide_kind", C.c_int), ("guide_strides", _IA), ("guide_vit_heads", C.c_int), ("guide_vit_patch", C.c_int), ("guide_vit_act", C.c_int),
         ("guide_feature_dim", C.c_int),
+        ("unet_transformer_depth", _IA), ("unet_level_heads", _IA), ("unet_add_time_dim", C.c_int), ("unet_add_text_dim", C.c_int),
     ]
 
 
@@ -65,6 +66,7 @@ def _declare(l):
     l.dd_set_prototypes.argtypes = [vp, vp, vp, i, i, i]
     l.dd_set_prompt.argtypes = [vp, vp, i, vp]
     l.dd_add_noise.argtypes = [vp, vp, vp, vp, i, i, vp]
+    l.dd_set_added_cond.argtypes = [vp, vp, vp, i, vp]
     l.dd_denoise_step.argtypes = [vp, vp, i, vp, vp, i, vp]
     l.dd_transform_guidance.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, vp]
     l.dd_direct_guidance.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, i, vp]
@@ -124,6 +126,11 @@ def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
         c.guide_expansion = g.mb_expand
     c.guide_vit_heads, c.guide_vit_patch, c.guide_vit_act = g.vit_heads, g.vit_patch, {"quick_gelu": 0, "gelu": 1}[g.vit_act]
     c.guide_feature_dim = g.feature_dim
+    if u.transformer_depth:
+        c.unet_transformer_depth = arr(u.transformer_depth)
+    if u.level_heads:
+        c.unet_level_heads = arr(u.level_heads)
+    c.unet_add_time_dim, c.unet_add_text_dim = u.add_time_dim, u.add_text_dim
     return c
 
 
@@ -244,6 +251,12 @@ class Engine:
         out = torch.empty(self.B, device=self.device, dtype=torch.float32)
         self._chk(self.L.dd_get_image_scores(self._h, _p(out), self.B, _stream()), "dd_get_image_scores")
         return out
+
+    def set_added_cond(self, text_embeds, time_ids):
+        """SDXL `added_cond_kwargs`: text_embeds [2B, add_text_dim], time_ids [2B, 6] (negative half first); after set_schedule."""
+        te, ti = self._f(text_embeds), self._f(time_ids)
+        assert te.shape[0] == 2 * self.B and tuple(ti.shape) == (2 * self.B, 6)
+        self._chk(self.L.dd_set_added_cond(self._h, _p(te), _p(ti), self.B, _stream()), "dd_set_added_cond")
 
     # ---- stage before the loop (SURVEY.md 8f-2; dataloader.py:633-661, 750-811) ------------------
     def vae_encode(self, images, noise=None, return_moments=False):

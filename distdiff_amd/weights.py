@@ -81,6 +81,9 @@ def synthetic_unet(cfg: EngineConfig, seed=0):
     b.linear("time_embedding.linear_1", temb, ch[0])
     b.linear("time_embedding.linear_2", temb, temb)
     b.conv("conv_in", ch[0], u.in_channels, 3)
+    if u.add_time_dim:                       # SDXL text_time conditioning: add_embedding = TimestepEmbedding(text + 6 time ids -> temb)
+        b.linear("add_embedding.linear_1", temb, u.add_text_dim + 6 * u.add_time_dim)
+        b.linear("add_embedding.linear_2", temb, temb)
 
     def resnet(p, cin, cout):
         b.norm(p + ".norm1", cin)
@@ -91,37 +94,44 @@ def synthetic_unet(cfg: EngineConfig, seed=0):
         if cin != cout:
             b.conv(p + ".conv_shortcut", cout, cin, 1)
 
-    def transformer(p, c):
+    def transformer(p, c, depth=1):
         b.norm(p + ".norm", c)
-        b.conv(p + ".proj_in", c, c, 1)
-        t = p + ".transformer_blocks.0"
-        for n in ("norm1", "norm2", "norm3"):
-            b.norm(t + "." + n, c)
-        for a, kv in (("attn1", c), ("attn2", u.cross_attention_dim)):
-            b.linear(t + "." + a + ".to_q", c, c, bias=False)
-            b.linear(t + "." + a + ".to_k", c, kv, bias=False)
-            b.linear(t + "." + a + ".to_v", c, kv, bias=False)
-            b.linear(t + "." + a + ".to_out.0", c, c)
-        b.linear(t + ".ff.net.0.proj", 8 * c, c)
-        b.linear(t + ".ff.net.2", c, 4 * c)
-        b.conv(p + ".proj_out", c, c, 1)
+        if u.transformer_depth:              # SDXL: use_linear_projection -> nn.Linear weights [C, C]
+            b.linear(p + ".proj_in", c, c)
+        else:
+            b.conv(p + ".proj_in", c, c, 1)
+        for d in range(depth):
+            t = p + ".transformer_blocks.%d" % d
+            for n in ("norm1", "norm2", "norm3"):
+                b.norm(t + "." + n, c)
+            for a, kv in (("attn1", c), ("attn2", u.cross_attention_dim)):
+                b.linear(t + "." + a + ".to_q", c, c, bias=False)
+                b.linear(t + "." + a + ".to_k", c, kv, bias=False)
+                b.linear(t + "." + a + ".to_v", c, kv, bias=False)
+                b.linear(t + "." + a + ".to_out.0", c, c)
+            b.linear(t + ".ff.net.0.proj", 8 * c, c)
+            b.linear(t + ".ff.net.2", c, 4 * c)
+        if u.transformer_depth:
+            b.linear(p + ".proj_out", c, c)
+        else:
+            b.conv(p + ".proj_out", c, c, 1)
 
     specs = unet_resnet_specs(cfg)
     for i, blk in enumerate(specs["down"]):
         for j, (cin, cout) in enumerate(blk):
             resnet("down_blocks.%d.resnets.%d" % (i, j), cin, cout)
             if u.down_attn[i]:
-                transformer("down_blocks.%d.attentions.%d" % (i, j), cout)
+                transformer("down_blocks.%d.attentions.%d" % (i, j), cout, u.depth(i))
         if i < len(ch) - 1:
             b.conv("down_blocks.%d.downsamplers.0.conv" % i, ch[i], ch[i], 3)
     resnet("mid_block.resnets.0", ch[-1], ch[-1])
-    transformer("mid_block.attentions.0", ch[-1])
+    transformer("mid_block.attentions.0", ch[-1], u.depth(len(ch) - 1))
     resnet("mid_block.resnets.1", ch[-1], ch[-1])
     for i, blk in enumerate(specs["up"]):
         for j, (cin, cout) in enumerate(blk):
             resnet("up_blocks.%d.resnets.%d" % (i, j), cin, cout)
             if u.up_attn[i]:
-                transformer("up_blocks.%d.attentions.%d" % (i, j), cout)
+                transformer("up_blocks.%d.attentions.%d" % (i, j), cout, u.depth(len(ch) - 1 - i))
         if i < len(ch) - 1:
             b.conv("up_blocks.%d.upsamplers.0.conv" % i, blk[-1][1], blk[-1][1], 3)
     b.norm("conv_norm_out", ch[0])

@@ -79,6 +79,11 @@ typedef struct dd_config {
   int guide_vit_heads, guide_vit_patch;
   int guide_vit_act;    /* 0 quick_gelu, 1 gelu (open_clip 'ViT-B-32': gelu) */
   int guide_feature_dim; /* D of encode_image: 2048 (ResNets) / 512 (ViT-B/32 projection) */
+  /* SDXL-style UNets (BASELINE.json configs[4]; unet/config.json transformer_layers_per_block, per-level attention_head_dim,
+   * addition_embed_type "text_time").  0 = the SD-1.x structure. */
+  int unet_transformer_depth[DD_MAX_LEVELS]; /* BasicTransformerBlocks per attention of a level (0: 1) */
+  int unet_level_heads[DD_MAX_LEVELS];       /* attention heads of a level (0: unet_num_heads) */
+  int unet_add_time_dim, unet_add_text_dim;  /* text_time conditioning: 6 time ids x add_time_dim sinusoids + pooled text embedding */
 } dd_config;
 
 typedef struct dd_sampler_params {
@@ -131,6 +136,11 @@ int dd_set_prototypes(dd_engine* e, const float* Pc, const float* Pg, int C, int
 /* embeds: DEVICE fp32 [2B, text_len, cross_dim], negative half first */
 int dd_set_prompt(dd_engine* e, const float* embeds, int B, void* stream);
 
+/* SDXL text_time conditioning (diffusers' added_cond_kwargs): text_embeds DEVICE fp32 [2B, add_text_dim], time_ids DEVICE fp32 [2B, 6]
+ * (original size, crop top-left, target size), negative half first like the prompt.  Builds the per-image, per-timestep bias tables
+ * emb = time_embedding(t) + add_embedding(cat[text_embeds, sinusoid(time_ids)]) -> time_emb_proj of every ResnetBlock2D.  Needed
+ * once per batch of images, after dd_set_schedule, when unet_add_time_dim > 0. */
+int dd_set_added_cond(dd_engine* e, const float* text_embeds, const float* time_ids, int B, void* stream);
 int dd_add_noise(dd_engine* e, const float* x, const float* noise, float* out, int B, int step_index, void* stream);
 int dd_denoise_step(dd_engine* e, const float* z, int step_index, float* z_prev_out, float* x0_out, int B, void* stream);
 int dd_transform_guidance(dd_engine* e, const float* z, const int* targets, const float* ch_e, const float* ch_b,

@@ -123,24 +123,32 @@ def _attention(sd, p, x, ctx, heads):
     return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
-def _transformer(sd, p, x, ctx, heads, groups):
+def _transformer(sd, p, x, ctx, heads, groups, depth=1):
+    """diffusers Transformer2DModel: `depth` BasicTransformerBlocks; proj_in / proj_out are 1x1 convolutions (SD-1.x) or, with
+    use_linear_projection (SDXL), nn.Linear applied after / before the NCHW <-> tokens permutation: the same arithmetic."""
     B, Cc, H, W = x.shape
     res = x
     h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
-    h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
-    h = h.permute(0, 2, 3, 1).reshape(B, H * W, Cc)
-    t = p + ".transformer_blocks.0"
-    n = F.layer_norm(h, (Cc,), sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], 1e-5)
-    h = h + _attention(sd, t + ".attn1", n, n, heads)
-    n = F.layer_norm(h, (Cc,), sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], 1e-5)
-    h = h + _attention(sd, t + ".attn2", n, ctx, heads)
-    n = F.layer_norm(h, (Cc,), sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], 1e-5)
-    proj = F.linear(n, sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
-    hid, gate = proj.chunk(2, dim=-1)
-    ff = F.linear(hid * F.gelu(gate), sd[t + ".ff.net.2.weight"], sd[t + ".ff.net.2.bias"])
-    h = h + ff
-    h = h.reshape(B, H, W, Cc).permute(0, 3, 1, 2)
-    h = F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    wi, wo = sd[p + ".proj_in.weight"], sd[p + ".proj_out.weight"]
+    if wi.dim() == 4:
+        h = F.conv2d(h, wi, sd[p + ".proj_in.bias"])
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    else:
+        h = F.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, Cc), wi, sd[p + ".proj_in.bias"])
+    for d in range(depth):
+        t = p + ".transformer_blocks.%d" % d
+        n = F.layer_norm(h, (Cc,), sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], 1e-5)
+        h = h + _attention(sd, t + ".attn1", n, n, heads)
+        n = F.layer_norm(h, (Cc,), sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], 1e-5)
+        h = h + _attention(sd, t + ".attn2", n, ctx, heads)
+        n = F.layer_norm(h, (Cc,), sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], 1e-5)
+        proj = F.linear(n, sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
+        hid, gate = proj.chunk(2, dim=-1)
+        h = h + F.linear(hid * F.gelu(gate), sd[t + ".ff.net.2.weight"], sd[t + ".ff.net.2.bias"])
+    if wo.dim() == 4:
+        h = F.conv2d(h.reshape(B, H, W, Cc).permute(0, 3, 1, 2), wo, sd[p + ".proj_out.bias"])
+    else:
+        h = F.linear(h, wo, sd[p + ".proj_out.bias"]).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
     return h + res
 
 
@@ -149,15 +157,23 @@ class UNetOracle:
 
     def __init__(self, cfg: EngineConfig, sd):
         self.cfg, self.sd = cfg, sd
+        self.added_cond = None       # SDXL: {"text_embeds": [B, add_text_dim], "time_ids": [B, 6]} (diffusers' added_cond_kwargs)
 
-    def __call__(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=False, **kw):
+    def __call__(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=False, added_cond_kwargs=None, **kw):
         u, sd = self.cfg.unet, self.sd
-        g, eps, heads = u.norm_num_groups, u.norm_eps, u.num_heads
+        g, eps = u.norm_num_groups, u.norm_eps
         B = sample.shape[0]
         t = torch.as_tensor(timestep).reshape(-1).expand(B)
         temb = timestep_embedding(t, u.block_out_channels[0], u.flip_sin_to_cos, u.freq_shift)
         temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
         temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+        if u.add_time_dim:
+            # addition_embed_type "text_time" (SDXL): emb += add_embedding(cat[text_embeds, add_time_proj(time_ids)])
+            ac = added_cond_kwargs or self.added_cond
+            tid = timestep_embedding(ac["time_ids"].reshape(-1), u.add_time_dim, True, 0.0).reshape(B, -1)
+            a = torch.cat([ac["text_embeds"], tid], dim=-1)
+            a = F.linear(a, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"])
+            temb = temb + F.linear(F.silu(a), sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
         h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
         skips = [h]
         nlev = len(u.block_out_channels)
@@ -165,21 +181,22 @@ class UNetOracle:
             for j in range(u.layers_per_block):
                 h = _resnet(sd, "down_blocks.%d.resnets.%d" % (i, j), h, temb, g, eps)
                 if u.down_attn[i]:
-                    h = _transformer(sd, "down_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, heads, g)
+                    h = _transformer(sd, "down_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, u.heads(i), g, u.depth(i))
                 skips.append(h)
             if i < nlev - 1:
                 p = "down_blocks.%d.downsamplers.0.conv" % i
                 h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=1)
                 skips.append(h)
         h = _resnet(sd, "mid_block.resnets.0", h, temb, g, eps)
-        h = _transformer(sd, "mid_block.attentions.0", h, encoder_hidden_states, heads, g)
+        h = _transformer(sd, "mid_block.attentions.0", h, encoder_hidden_states, u.heads(nlev - 1), g, u.depth(nlev - 1))
         h = _resnet(sd, "mid_block.resnets.1", h, temb, g, eps)
         for i in range(nlev):
             for j in range(u.layers_per_block + 1):
                 h = torch.cat([h, skips.pop()], dim=1)
                 h = _resnet(sd, "up_blocks.%d.resnets.%d" % (i, j), h, temb, g, eps)
                 if u.up_attn[i]:
-                    h = _transformer(sd, "up_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, heads, g)
+                    h = _transformer(sd, "up_blocks.%d.attentions.%d" % (i, j), h, encoder_hidden_states, u.heads(nlev - 1 - i), g,
+                                     u.depth(nlev - 1 - i))
             if i < nlev - 1:
                 p = "up_blocks.%d.upsamplers.0.conv" % i
                 h = F.interpolate(h, scale_factor=2.0, mode="nearest")
