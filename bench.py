@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16, help="images per step per GPU (train_batch_size)")
-    ap.add_argument("--config", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--config", default="sd15", choices=["sd15", "tiny", "sdxl"],
+                    help="sd15 = BASELINE configs[1] (the metric's workload); sdxl = the SDXL-base UNet at 1024x1024 (configs[4] structure, bf16)")
     ap.add_argument("--guidance", default="transform_guidance", choices=["transform_guidance", "direct_guidance", "none"])
     ap.add_argument("--strength", type=float, default=0.5)
     ap.add_argument("--schedule_steps", type=int, default=50)
@@ -151,14 +152,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from distdiff_amd.config import sd15_config, tiny_config
+    from distdiff_amd.config import sd15_config, sdxl_config, tiny_config
     from distdiff_amd.engine import Engine
     from distdiff_amd.launcher import build_engine_distributed, shard_range
     from distdiff_amd.scheduler import DDIMSchedule
     from distdiff_amd.weights import synthetic_weights
 
     B = a.batch
-    cfg = sd15_config(max_batch=B) if a.config == "sd15" else tiny_config(max_batch=B)
+    cfg = {"sd15": sd15_config, "tiny": tiny_config, "sdxl": sdxl_config}[a.config](max_batch=B)
     C_cls, K = 100, 3
     t_setup = time.time()
     guided = a.guidance != "none"
@@ -201,6 +202,10 @@ def main():
     targets = torch.randint(0, C_cls, (len(mine),), generator=gd).to(dev)
     emb = torch.randn(2 * B, cfg.text_len, cfg.unet.cross_attention_dim, generator=gd).to(dev)
     eng.set_prompt(emb)
+    if cfg.unet.add_time_dim:          # SDXL text_time conditioning: pooled text embeddings + (original size, crop, target size)
+        S = 8.0 * L
+        eng.set_added_cond(torch.randn(2 * B, cfg.unet.add_text_dim, generator=gd).to(dev),
+                           torch.tensor([[S, S, 0.0, 0.0, S, S]] * (2 * B)).to(dev))
     si = int((1 - a.strength) * len(ts))
     gfirst = len(ts) - a.guidance_step
     gtype = None if not guided else a.guidance
@@ -249,7 +254,9 @@ def main():
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SD-1.5 shapes %dx%d, %d-step DDIM schedule, strength %.2f (%d executed steps), "
+            "config": {"workload": ("BASELINE configs[4] structure: SDXL-base UNet shapes (bf16 attention), " if a.config == "sdxl" else
+                                    "BASELINE configs[1]: SD-1.5 shapes ") +
+                                   "%dx%d, %d-step DDIM schedule, strength %.2f (%d executed steps), "
                                    "CFG 7.5, %s P=%d (class+group prototypes C=100 K=3 D=%d, ResNet-50 guide), final VAE decode"
                                    % (8 * L, 8 * L, len(ts), a.strength, n_exec, a.guidance, a.guidance_period, D),
                        "images_per_step_per_gpu": B, "sharding": "image shards per rank (generate_data.py:1003-1007), no data-path collective",

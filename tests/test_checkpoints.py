@@ -162,3 +162,27 @@ def test_dataset_listings(tmp_path):
     paths, labels, cls = load_train_listing("stanford_cars", str(root))
     assert len(cls) == 196 and cls[0] == "1990 Make0 Model Type" and cls[5] == "1995 Make5 Model Type"
     assert len(paths) == 400 and labels[:3] == [0, 5, 10] and paths[0].endswith(os.path.join("stanford_cars", "cars_train", "00001.jpg"))
+
+
+def test_sdxl_unet_config_is_read_from_the_model_dir(tmp_path):
+    """unet/config.json of an SDXL-style UNet (transformer_layers_per_block, per-level attention_head_dim, addition_embed_type text_time,
+    use_linear_projection: BASELINE.json configs[4]) populates the engine config; other addition_embed_types are refused."""
+    from distdiff_amd.config import tiny_sdxl_config
+    cfg = tiny_sdxl_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=2, encoders=True)
+    assert tuple(w["unet"]["down_blocks.1.attentions.0.proj_in.weight"].shape) == (128, 128)              # nn.Linear, not a 1x1 conv
+    assert "down_blocks.2.attentions.0.transformer_blocks.2.attn2.to_k.weight" in w["unet"] and "add_embedding.linear_1.weight" in w["unet"]
+    assert tuple(w["unet"]["add_embedding.linear_1.weight"].shape) == (256, 24 + 6 * 8)
+    root = str(tmp_path / "sdxl-tiny")
+    write_model_dir(root, cfg, w)
+    u = json.load(open(os.path.join(root, "unet", "config.json")))
+    u.update({"attention_head_dim": [2, 2, 4], "transformer_layers_per_block": [1, 2, 3], "addition_embed_type": "text_time",
+              "addition_time_embed_dim": 8, "projection_class_embeddings_input_dim": 24 + 6 * 8, "use_linear_projection": True})
+    json.dump(u, open(os.path.join(root, "unet", "config.json"), "w"))
+    got = from_model_dir(root, cfg.latent_size, 2)
+    got.unet.num_heads = cfg.unet.num_heads          # the fallback head count is unused when every level has its own
+    assert got.unet == cfg.unet
+    u["addition_embed_type"] = "image"
+    json.dump(u, open(os.path.join(root, "unet", "config.json"), "w"))
+    with pytest.raises(NotImplementedError):
+        from_model_dir(root)
