@@ -399,6 +399,9 @@ def main(argv=None):
     if args.gpus > 1 and "RANK" not in os.environ:
         # the in-process fan-out that replaces single_exp.sh / expand_diff.sh's one shell per GPU: start the ranks before any GPU call
         from .launcher import spawn_ranks
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU in this (parent) process
+        if have < args.gpus:
+            raise SystemExit("--gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
         return spawn_ranks(args.gpus, argv)
     distributed = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank, world, device = 0, 1, None
