@@ -145,19 +145,28 @@ struct Profiler {   // HIP-event timing of every op, by kernel family (dd_profil
   bool on = false;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  struct Rec { int fam; double flops; size_t e0; int M, N, K, bwd; };
+  struct Rec { int fam; double flops; size_t e0, e1; int M, N, K, bwd; };
   std::vector<Rec> recs;
+  bool chain = false;    // the last event recorded is the end of the previous op of the same run: it doubles as this op's start
   hipEvent_t get() {
     if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
     return pool[used++];
   }
+  void new_run() { chain = false; }   // other launches may sit between two program runs: the next op records its own start
   void begin(int fam, double flops, hipStream_t s, int M = 0, int N = 0, int K = 0, int bwd = 0) {
     if (!on) return;
-    Rec r; r.fam = fam; r.flops = flops; r.e0 = used; r.M = M; r.N = N; r.K = K; r.bwd = bwd;
-    hipEventRecord(get(), s); get();
+    Rec r; r.fam = fam; r.flops = flops; r.M = M; r.N = N; r.K = K; r.bwd = bwd;
+    if (chain) r.e0 = used - 1;                      // one event per op boundary: half the recording overhead inside the timed step
+    else { r.e0 = used; hipEventRecord(get(), s); }
+    r.e1 = 0;
     recs.push_back(r);
   }
-  void end(hipStream_t s) { if (on) hipEventRecord(pool[recs.back().e0 + 1], s); }
+  void end(hipStream_t s) {
+    if (!on) return;
+    recs.back().e1 = used;
+    hipEventRecord(get(), s);
+    chain = true;
+  }
 };
 
 struct Ctx {  // per-call execution context
@@ -707,6 +716,7 @@ void run_conv_f32_bwd(const Program& P, const Op& op, const Ctx& c) {
 
 void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) {
   if (op_end < 0) op_end = (int)P.ops.size();
+  if (c.prof) c.prof->new_run();
   for (int i = op_begin; i < op_end; ++i) {
     const Op& op = P.ops[i];
     const int fam = (op.kind == OP_CONV && !P.f32) ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
@@ -851,6 +861,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
 }
 
 void run_bwd(const Program& P, const Ctx& c) {
+  if (c.prof) c.prof->new_run();
   for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
     const Op& op = P.ops[i];
     const int fam = (op.kind == OP_CONV && !P.f32) ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
@@ -2145,6 +2156,7 @@ int dd_profile_enable(dd_engine* E, int on) {
   if (!E) return DD_ERR_ARG;
   E->prof.on = on != 0;
   E->prof.used = 0;
+  E->prof.chain = false;
   E->prof.recs.clear();
   return DD_OK;
 }
@@ -2158,12 +2170,12 @@ int dd_profile_read(dd_engine* E, double* out12) {
     if (dump) fprintf(dump, "fam,bwd,M,N,K,flops,ms\n");
     for (auto& r : E->prof.recs) {
       float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, E->prof.pool[r.e0], E->prof.pool[r.e0 + 1]));
+      HIPCHK(hipEventElapsedTime(&ms, E->prof.pool[r.e0], E->prof.pool[r.e1]));
       if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%.5f\n", r.fam, r.bwd, r.M, r.N, r.K, r.flops, ms);
       out12[r.fam * 3 + 0] += ms; out12[r.fam * 3 + 1] += r.flops; out12[r.fam * 3 + 2] += 1;
     }
     if (dump) fclose(dump);
-    E->prof.used = 0; E->prof.recs.clear();
+    E->prof.used = 0; E->prof.chain = false; E->prof.recs.clear();
   });
 }
 

@@ -4,7 +4,7 @@ The reference fans out one OS process per GPU by hand, `CUDA_VISIBLE_DEVICES=k p
 (single_exp.sh:4-8, scripts/exps/expand_diff.sh:19-24), and every process loads its own copy of the weights from disk and repeats the
 prototype extraction over the whole training set.  Here `generate_data.py --gpus N` (or `expand_diff.sh <EXPAND_NUM>`) starts N ranks,
 one per GPU, BEFORE any GPU call; rank 0 loads and packs the weights once and broadcasts the PACKED device buffers (bf16 MFMA layouts
-+ fp32 guide / norm / embedding tables, ~2.4 GB for SD-1.x) over RCCL/xGMI in ~1 GiB buckets -- few, large collectives, because an
++ fp32 guide / norm / embedding tables, 3.8 GB for SD-1.x incl. the input-gradient packings) over RCCL/xGMI in ~1 GiB buckets -- few, large collectives, because an
 xGMI ring is per-link bound -- ; prototype features are computed on per-rank shards and all-gathered; the units of work
 (train image i, expand index j) shard with the reference's own partition function (generate_data.py:1003-1007) and need no
 collective on the data path; image counts and elapsed time are all-reduced at the end for the node-level images/s.
