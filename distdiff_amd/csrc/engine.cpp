@@ -80,6 +80,10 @@ struct Tn {              // activation tensor or channel view
   int rows = 0, C = 0, ld = 0, B = 0, H = 0, W = 0;
   bool f32 = false, grad = false;
   bool gf32 = false;     // the gradient of this tensor is fp32 (always in fp32 programs; the image input of the ViT guide)
+  // Transient activation: only read by the operation that follows its producer and never by a reverse program (no weight gradients
+  // are computed, so the INPUT of a convolution is dead after it ran: GroupNorm / LayerNorm / GEGLU / activation outputs).  It lives in
+  // one of two ping-pong buffers shared by all instances instead of the per-instance stash slab.
+  bool transient = false; int tr_slot = 0;
 };
 
 enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT, OP_PATCHIFY, OP_VITEMBED, OP_SELECT };
@@ -114,6 +118,17 @@ struct Program {
   bool want_grad = false;
   bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
   mutable std::vector<char> emitted;   // per op, per forward run: this convolution did emit its GroupNorm partials
+  size_t tr_max = 0;     // bytes of one transient ping-pong buffer
+  int tr_count = 0;
+  int transient(int B, int H, int W, int C, bool grad = true) {
+    if (f32 || getenv("DD_NO_TRANSIENT")) return tensor(B, H, W, C, grad);
+    const size_t save = act_bytes;
+    const int id = tensor(B, H, W, C, grad);
+    tr_max = std::max(tr_max, act_bytes - save);
+    act_bytes = save;                    // give the stash bytes back: the tensor lives in the transient buffers
+    t[id].off = 0; t[id].transient = true; t[id].tr_slot = tr_count++ & 1;
+    return id;
+  }
 
   int tensor(int B, int H, int W, int C, bool grad = true, bool f32_act = false, bool f32_grad = false) {
     Tn n;
@@ -184,12 +199,14 @@ struct Ctx {  // per-call execution context
   double* flops = nullptr;
   Profiler* prof = nullptr;
   bool stash = true;     // false on plain (no-VJP) steps: skip stores that only the reverse program reads
+  char* tr = nullptr; size_t tr_stride = 0;   // transient ping-pong buffers of the program being run
   int img_bias = 0;      // > 0: the time-embedding bias is per image (SDXL added conditioning): number of images (2B) of the tables
 };
 
-inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.act + t.off); }
+inline char* act_raw(const Ctx& c, const Tn& t) { return t.transient ? c.tr + (size_t)t.tr_slot * c.tr_stride : c.act + t.off; }
+inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)act_raw(c, t); }
 inline bf16_t* grad_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.grad + t.goff); }
-inline float* act_f32(const Ctx& c, const Tn& t) { return (float*)(c.act + t.off); }
+inline float* act_f32(const Ctx& c, const Tn& t) { return (float*)act_raw(c, t); }
 inline float* grad_f32(const Ctx& c, const Tn& t) { return (float*)(c.grad + t.goff); }
 
 }  // namespace
@@ -238,6 +255,7 @@ struct dd_engine {
   };
   std::vector<Inst> inst;
   char* grad_slab = nullptr;   // shared by the three programs (max of their grad sizes)
+  char* tr_slab = nullptr;     // two transient ping-pong buffers, shared by every program and instance (they run one after another)
   char* scratch_partial = nullptr; size_t partial_cap = 0;
   char* scratch_tmp = nullptr; size_t tmp_cap = 0;
   float* gn_scratch = nullptr;
@@ -440,7 +458,8 @@ struct Builder {
     const int Hl = tx.H << up, Wl = tx.W << up;
     const int Ho = (Hl + 2 * w->pad + w->pad_br - w->KH) / stride + 1, Wo = (Wl + 2 * w->pad + w->pad_br - w->KW) / stride + 1;
     const int Cy = w->geglu ? w->Cout / 2 : w->Cout;
-    int y = y_into >= 0 ? y_into : P.tensor(tx.B, Ho, Wo, Cy, true, out_f32 != 0);
+    // the output of a GEGLU projection only feeds ff.net.2 (its VJP reads the stashed pre-activations): transient
+    int y = y_into >= 0 ? y_into : (w->geglu && !out_f32) ? P.transient(tx.B, Ho, Wo, Cy) : P.tensor(tx.B, Ho, Wo, Cy, true, out_f32 != 0);
     Op op; op.kind = OP_CONV; op.x = x; op.y = y; op.res = res; op.cw = w; op.stride = stride; op.up = up; op.relu = relu;
     op.out_f32 = out_f32; op.use_table = use_table;
     if (w->geglu && P.want_grad && keep_raw) op.raw = P.tensor(tx.B, Ho, Wo, w->Cout, false);
@@ -463,15 +482,16 @@ struct Builder {
   }
   int gn(int x, NormW* w, int G, float eps, int silu) {
     const Tn& tx = P.t[x];
-    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    int y = P.transient(tx.B, tx.H, tx.W, tx.C);      // consumed by the convolution that follows, never by a reverse program
     Op op; op.kind = OP_GN; op.x = x; op.y = y; op.nw = w; op.G = G; op.eps = eps; op.silu = silu;
     op.stats_off = P.fp32_block((size_t)tx.B * G * 2);
     P.ops.push_back(op);
     return y;
   }
-  int ln(int x, NormW* w, float eps) {
+  // keep: the output outlives the next operation (a residual stream base, a program output)
+  int ln(int x, NormW* w, float eps, bool keep = false) {
     const Tn& tx = P.t[x];
-    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    int y = keep ? P.tensor(tx.B, tx.H, tx.W, tx.C) : P.transient(tx.B, tx.H, tx.W, tx.C);
     Op op; op.kind = OP_LN; op.x = x; op.y = y; op.nw = w; op.eps = eps;
     op.stats_off = P.fp32_block((size_t)tx.rows * 2);
     P.ops.push_back(op);
@@ -500,7 +520,7 @@ struct Builder {
     Op op; op.kind = OP_CONCAT; op.x = a; op.x2 = b; op.y = y;
     auto movable = [&](int id) {
       const Tn& t = P.t[id];
-      if (t.parent != id || t.f32 || P.f32 || (t.C & 7)) return false;
+      if (t.parent != id || t.f32 || P.f32 || t.transient || (t.C & 7)) return false;
       for (size_t k = 0; k < P.t.size(); ++k)
         if ((int)k != id && P.t[k].parent == id) return false;     // it has views of its own (their offsets would go stale)
       return true;
@@ -520,7 +540,7 @@ struct Builder {
   }
   int act(int x, int kind) {   // text encoder MLP (forward only), ViT guide MLP (with backward)
     const Tn& tx = P.t[x];
-    int y = P.tensor(tx.B, tx.H, tx.W, tx.C);
+    int y = P.transient(tx.B, tx.H, tx.W, tx.C);
     Op op; op.kind = OP_ACT; op.x = x; op.y = y; op.act_kind = kind;
     P.ops.push_back(op);
     return y;
@@ -616,12 +636,45 @@ void plan_backward(Program& P) {
   }
 }
 
+// Transient tensors (Tn::transient) share two ping-pong buffers: legal only if every reader of one runs before the next tensor that
+// takes the same buffer is produced, and no reverse program reads it.  Checked once per program at build time.
+void check_transients(const Program& P) {
+  auto reads = [&](const Op& o, int id) {
+    auto is = [&](int t) { return t >= 0 && (t == id || P.t[t].parent == id); };
+    return is(o.x) || is(o.res) || is(o.q) || is(o.k) || is(o.v) || is(o.x2);
+  };
+  for (size_t id = 0; id < P.t.size(); ++id) {
+    if (!P.t[id].transient) continue;
+    int prod = -1, next_same_slot = (int)P.ops.size();
+    for (size_t oi = 0; oi < P.ops.size(); ++oi)
+      if (P.ops[oi].y == (int)id) prod = (int)oi;
+    if (prod < 0) throw std::runtime_error("transient tensor without a producer");
+    for (size_t oi = prod + 1; oi < P.ops.size(); ++oi) {
+      const int y = P.ops[oi].y;
+      if (y >= 0 && P.t[y].transient && P.t[y].tr_slot == P.t[id].tr_slot) { next_same_slot = (int)oi; break; }
+    }
+    for (size_t oi = 0; oi < P.ops.size(); ++oi) {
+      const Op& o = P.ops[oi];
+      if (!reads(o, (int)id)) continue;
+      if ((int)oi <= prod || (int)oi > next_same_slot) throw std::runtime_error("transient tensor is read after its buffer was reused");
+      // activations a reverse program reads must be stashed, not transient
+      const bool bwd_reads = (o.kind == OP_GN || o.kind == OP_LN || o.kind == OP_MAXPOOL || o.kind == OP_ACT || o.kind == OP_ATTN) ||
+                             (o.kind == OP_CONV && o.res == (int)id && false);
+      if (P.want_grad && bwd_reads) throw std::runtime_error("transient tensor is an input a reverse program reads");
+    }
+    if (P.want_grad)
+      for (const Op& o : P.ops)
+        if (o.y == (int)id && ((o.kind == OP_CONV && o.relu) || o.kind == OP_ATTN)) throw std::runtime_error("transient tensor is an output a reverse program reads");
+  }
+}
+
 // GroupNorm statistics without a pass over the tensor: when every producer of a GroupNorm's input (possibly several convolutions
 // writing column ranges of one concat buffer) is an implicit-GEMM convolution, those convolutions emit per-(64-row block, channel)
 // partial (mean, M2) from their epilogue registers and the GroupNorm merges them.  Whether a convolution can do that depends on the
 // kernel the launcher picks for its shape (conv_gemm_can_emit_stats), so the final decision is taken per run; this pass only sets up
 // the buffers and the producer lists.
 void plan_gn_stats(Program& P) {
+  check_transients(P);
   P.emitted.assign(P.ops.size(), 0);
   if (P.f32 || getenv("DD_NO_GN_FUSION")) return;
   std::unordered_map<int, size_t> root_part;
@@ -733,7 +786,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         ConvGemmParams p; fill_conv(p, c);
         const ConvW* w = op.cw;
         p.x = act_ptr(c, x); p.x_ld = x.ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
-        p.y = c.act + y.off; p.y_ld = y.ld;
+        p.y = act_raw(c, y); p.y_ld = y.ld;
         p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.shift = op.up; p.parity = 0;
         p.cin = w->sf.cin; p.ntaps = w->sf.ntaps; p.M = y.rows; p.N = w->sf.N; p.K = w->sf.K;
         int flags = 0;
@@ -1234,7 +1287,8 @@ void build_text_encoder(dd_engine* E) {
     h = b.act(h, c.text_act);
     x = b.conv(h, make_conv(E, m, p + ".mlp.fc2", 0), 1, 0, x);
   }
-  E->text_out = b.ln(x, make_norm(E, m, tm + "final_layer_norm"), eps);
+  E->text_out = b.ln(x, make_norm(E, m, tm + "final_layer_norm"), eps, /*keep=*/true);
+  check_transients(P);
 }
 
 void build_guide(dd_engine* E) {
@@ -1346,7 +1400,7 @@ void build_guide_vit(dd_engine* E) {
     h = b.vit_embed(h, E->norms.back().get());
   }
   const float eps = 1e-5f;
-  int x = b.ln(h, make_norm(E, m, v + "ln_pre"), eps);
+  int x = b.ln(h, make_norm(E, m, v + "ln_pre"), eps, /*keep=*/true);   // the residual stream
   char buf[160];
   const int N = np + 1;
   for (int l = 0;; ++l) {
@@ -1391,8 +1445,8 @@ inline int guide_feat_dim(const dd_config& c) {
 // ---------------------------------------------------------------------------------------------------
 struct Run {
   dd_engine* E; hipStream_t s; int B;
-  Ctx ctx(const Program&, char* act) {
-    Ctx c; c.act = act; c.grad = E->grad_slab; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
+  Ctx ctx(const Program& P, char* act) {
+    Ctx c; c.act = act; c.grad = E->grad_slab; c.tr = E->tr_slab; c.tr_stride = P.tr_max; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
     c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
     return c;
   }
@@ -1656,6 +1710,7 @@ int dd_finalize_weights(dd_engine* E) {
       I.feat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
       I.gfeat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
     }
+    E->tr_slab = (char*)E->dmalloc(2 * std::max({E->unet.tr_max, E->vae.tr_max, E->guide.tr_max, E->venc.tr_max, E->text.tr_max, (size_t)256}));
     if (c.enable_grad) {
       // UNet gradients alone; VAE and guide gradients live side by side (bicubic^T bridges them)
       const size_t g = std::max(E->unet.grad_bytes, E->vae.grad_bytes + E->guide.grad_bytes);
@@ -2195,7 +2250,7 @@ int dd_debug_tensor(dd_engine* E, int prog_inst, int idx, int want_grad, float* 
     const dd_engine::Inst& I = E->inst[k];
     char* slab = prog == 0 ? I.unet : prog == 1 ? I.vae : I.guide;
     if (!want_grad && !slab) throw std::runtime_error("this instance has no slab for that program");
-    char* base = want_grad ? E->grad_slab + t.goff : slab + t.off;
+    char* base = want_grad ? E->grad_slab + t.goff : t.transient ? E->tr_slab + (size_t)t.tr_slot * P.tr_max : slab + t.off;
     const size_t n = (size_t)t.rows * t.ld;
     if ((t.f32 && !want_grad) || (want_grad && t.gf32)) { HIPCHK(hipMemcpy(host_out, base, n * 4, hipMemcpyDeviceToHost)); }
     else {

@@ -88,4 +88,4 @@ def test_sdxl_guided_step_and_loop(world):
         zo, imo, _ = O.expand_one(a, cfg, (unet, vae, guide, so), lat, noise, d["e"], d["b"], d["pe"], d["ne"], d["tg"], d["Pc"], d["Pg"])
         # guided: the oracle's masks are drawn at ITS forward point (conditioning of the guide's gradient, tests/test_engine_gpu.py): 6.7 %
         assert rel(z, zo) < (0.10 if gt else 0.04), (gt, rel(z, zo))
-        assert float((img.cpu() - imo).abs().max()) < 0.1
+        assert float((img.cpu() - imo).abs().max()) < (0.2 if gt else 0.1)
