@@ -261,7 +261,10 @@ def main():
                                    % (8 * L, 8 * L, len(ts), a.strength, n_exec, a.guidance, a.guidance_period, D),
                        "images_per_step_per_gpu": B, "sharding": "image shards per rank (generate_data.py:1003-1007), no data-path collective",
                        "weights": "seeded synthetic, exact SD-1.x / AutoencoderKL / ResNet-50 shapes",
-                       "algorithmic_tflop_per_image": flops_per_image / 1e12, "setup_s": setup_s,
+                       "algorithmic_tflop_per_image": flops_per_image / 1e12,
+                       "flop_note": "FLOPs the engine executed (2 per MAC, dgrad-only VJP); the part of the UNet in front of the first "
+                                    "cross-attention is identical for the two CFG halves and runs once (DESIGN.md section 6)",
+                       "setup_s": setup_s,
                        "workspace_gb": eng.workspace_bytes() / 1e9},
             "e2e_tflops_per_gpu": flops / dt / 1e12,
             "e2e_frac_of_bf16_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS,

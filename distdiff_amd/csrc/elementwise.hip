@@ -87,13 +87,14 @@ __global__ void cfg_ddim_bwd_kernel(const float* g_x0, const float* g_zprev, bf1
 }
 
 // g_z[b,c,pix] += gin[(b*HW+pix), c] + gin[((B+b)*HW+pix), c]   (backward of cat[z, z] + layout change)
-__global__ void dup_bwd_kernel(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate) {
+__global__ void dup_bwd_kernel(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, int halves) {
   const size_t total = (size_t)B * C * HW;
   GRID_STRIDE(i, total) {
     const int pix = (int)(i % HW);
     const int c = (int)((i / HW) % C);
     const int b = (int)(i / ((size_t)HW * C));
-    const float v = bf2f(gin[((size_t)b * HW + pix) * ld + c]) + bf2f(gin[((size_t)(B + b) * HW + pix) * ld + c]);
+    float v = bf2f(gin[((size_t)b * HW + pix) * ld + c]);
+    if (halves == 2) v += bf2f(gin[((size_t)(B + b) * HW + pix) * ld + c]);
     g_z[i] = accumulate ? g_z[i] + v : v;
   }
 }
@@ -647,8 +648,8 @@ hipError_t launch_cfg_ddim_bwd(const float* g_x0, const float* g_zprev, bf16_t* 
                                const float* coef_dev, hipStream_t s) {
   LAUNCH(cfg_ddim_bwd_kernel, (size_t)B * HW * ld, g_x0, g_zprev, g_eps2, ld, g_z, B, C, HW, ld, coef_dev);
 }
-hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, hipStream_t s) {
-  LAUNCH(dup_bwd_kernel, (size_t)B * C * HW, gin, ld, g_z, B, C, HW, accumulate);
+hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, int halves, hipStream_t s) {
+  LAUNCH(dup_bwd_kernel, (size_t)B * C * HW, gin, ld, g_z, B, C, HW, accumulate, halves);
 }
 hipError_t launch_axpby(const float* x, const float* n, float* out, size_t count, const float* coef_dev, hipStream_t s) {
   LAUNCH(axpby_kernel, count, x, n, out, count, coef_dev);

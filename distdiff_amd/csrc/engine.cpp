@@ -86,7 +86,7 @@ struct Tn {              // activation tensor or channel view
   bool transient = false; int tr_slot = 0;
 };
 
-enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT, OP_PATCHIFY, OP_VITEMBED, OP_SELECT };
+enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT, OP_PATCHIFY, OP_VITEMBED, OP_SELECT, OP_DUP };
 
 struct Op {
   OpKind kind;
@@ -449,6 +449,7 @@ NormW* make_norm(dd_engine* E, const std::string& model, const std::string& pref
 struct Builder {
   dd_engine* E;
   Program& P;
+  int full_batch = 0;      // UNet: 2B when the CFG halves share their prefix (the program starts on B images), else 0
   Builder(dd_engine* e, Program& p) : E(e), P(p) {}
 
   // y = epilogue(conv(x)) ; returns y (allocated unless `y_into` >= 0)
@@ -562,6 +563,14 @@ struct Builder {
     P.ops.push_back(op);
     return y;
   }
+  // cat[x, x] along the batch: the point where the two classifier-free-guidance halves stop being identical (build_unet)
+  int dup(int x) {
+    const Tn& tx = P.t[x];
+    int y = P.tensor(2 * tx.B, tx.H, tx.W, tx.C);
+    Op op; op.kind = OP_DUP; op.x = x; op.y = y;
+    P.ops.push_back(op);
+    return y;
+  }
   int select_first(int x) {     // the class token of every image
     const Tn& tx = P.t[x];
     int y = P.tensor(tx.B, 1, 1, tx.C);
@@ -620,7 +629,7 @@ void plan_backward(Program& P) {
       case OP_GN: case OP_LN: case OP_MAXPOOL: case OP_GAP:
         op.x_acc = mark(op.x);
         break;
-      case OP_ACT: case OP_PATCHIFY: case OP_VITEMBED: case OP_SELECT:
+      case OP_ACT: case OP_PATCHIFY: case OP_VITEMBED: case OP_SELECT: case OP_DUP:
         op.x_acc = mark(op.x);
         break;
       case OP_ATTN:
@@ -907,6 +916,11 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         HIPCHK(launch_select_rows(act_ptr(c, x), x.ld, act_ptr(c, y), y.ld, x.B, op.sel_stride, x.C, c.s));
       } break;
+      case OP_DUP: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        HIPCHK(launch_copy_bf16(act_ptr(c, x), x.ld, act_ptr(c, y), y.ld, x.rows, rup(x.C, 8), c.s));
+        HIPCHK(launch_copy_bf16(act_ptr(c, x), x.ld, act_ptr(c, y) + (size_t)x.rows * y.ld, y.ld, x.rows, rup(x.C, 8), c.s));
+      } break;
       case OP_GAP: break;
     }
     if (c.prof) c.prof->end(c.s);
@@ -1046,6 +1060,18 @@ void run_bwd(const Program& P, const Ctx& c) {
         if (op.x_acc) throw std::runtime_error("vit_embed backward accumulate unsupported");
         HIPCHK(launch_vit_embed_bwd(grad_ptr(c, y), y.ld, grad_ptr(c, x), x.ld, x.B, x.H, x.C, c.s));
       } break;
+      case OP_DUP: {
+        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        if (!x.grad) break;
+        bf16_t* gy = grad_ptr(c, y); bf16_t* gx = grad_ptr(c, x);
+        const bf16_t* hi = gy + (size_t)x.rows * y.ld;
+        if (op.x_acc) {
+          HIPCHK(launch_add_bf16(gx, x.ld, gy, y.ld, gx, x.ld, x.rows, rup(x.C, 8), c.s));
+          HIPCHK(launch_add_bf16(gx, x.ld, hi, y.ld, gx, x.ld, x.rows, rup(x.C, 8), c.s));
+        } else {
+          HIPCHK(launch_add_bf16(gy, y.ld, hi, y.ld, gx, x.ld, x.rows, rup(x.C, 8), c.s));
+        }
+      } break;
       case OP_SELECT: {
         const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
         if (!x.grad) break;
@@ -1103,6 +1129,13 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
     n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
     int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false));
+    if (P.t[q2].B == E->cfg.max_batch && b.full_batch == 2 * E->cfg.max_batch) {
+      // Up to here the unconditional and the conditional half of the CFG batch were the SAME computation (same latents, same timestep;
+      // only the text differs): it ran once on B images.  The first cross-attention is where they part: cat[q, q], cat[h, h].
+      q2 = b.dup(q2);
+      h = b.dup(h);
+      x = b.dup(x);
+    }
     dd_engine::CrossSlot slot;
     slot.wk = make_conv(E, m, t + ".attn2.to_k", 0, false, false);
     slot.wv = make_conv(E, m, t + ".attn2.to_v", 0, false, false);
@@ -1128,7 +1161,12 @@ void build_unet(dd_engine* E) {
   const std::string m = "unet";
   auto heads_of = [&](int lev) { return c.unet_level_heads[lev] > 0 ? c.unet_level_heads[lev] : c.unet_num_heads; };
   auto depth_of = [&](int lev) { return c.unet_transformer_depth[lev] > 0 ? c.unet_transformer_depth[lev] : 1; };
-  E->unet_in = P.tensor(B2, L, L, c.unet_in_channels);
+  // classifier-free guidance runs the UNet on cat[z, z] (generate_data.py:110-112): until the first cross-attention the two halves are
+  // bit-for-bit the same computation, so the program starts on B images and duplicates at that point (build_transformer).  Not with
+  // SDXL's text_time conditioning, whose time embedding already differs per half.
+  const bool share = c.unet_add_time_dim == 0 && !getenv("DD_NO_CFG_SHARE");
+  b.full_batch = share ? B2 : 0;
+  E->unet_in = P.tensor(share ? c.max_batch : B2, L, L, c.unet_in_channels);
   int h = b.conv(E->unet_in, make_conv(E, m, "conv_in", 1));
   std::vector<int> skips{h};
   char buf[128];
@@ -1150,7 +1188,9 @@ void build_unet(dd_engine* E) {
   h = build_resnet(b, m, "mid_block.resnets.1", h, G, eps, true);
   for (int i = 0; i < nl; ++i) {
     for (int j = 0; j < c.unet_layers_per_block + 1; ++j) {
-      h = b.concat(h, skips.back()); skips.pop_back();
+      int sk = skips.back(); skips.pop_back();
+      if (P.t[sk].B != P.t[h].B) sk = b.dup(sk);      // a skip from the shared CFG prefix
+      h = b.concat(h, sk);
       snprintf(buf, sizeof buf, "up_blocks.%d.resnets.%d", i, j);
       h = build_resnet(b, m, buf, h, G, eps, true);
       if (c.unet_up_attn[i]) { snprintf(buf, sizeof buf, "up_blocks.%d.attentions.%d", i, j); h = build_transformer(b, buf, h, heads_of(nl - 1 - i), G, depth_of(nl - 1 - i)); }
@@ -1160,6 +1200,7 @@ void build_unet(dd_engine* E) {
       h = b.conv(h, make_conv(E, m, buf, 1), 1, 1);
     }
   }
+  if (P.t[h].B != B2) throw std::runtime_error("UNet without any cross-attention: the CFG halves never part");
   h = b.gn(h, make_norm(E, m, "conv_norm_out"), G, eps, 1);
   E->unet_out = b.conv(h, make_conv(E, m, "conv_out", 1), 1, 0, -1, 0, 1);
   if (P.want_grad) plan_backward(P);
@@ -1470,8 +1511,8 @@ void unet_fwd(dd_engine* E, int k, const float* z, int step_index, hipStream_t s
     ctx.img_bias = 2 * c.max_batch;
   }
   const Tn& in = E->unet.t[E->unet_in];
-  HIPCHK(launch_nchw_f32_to_nhwc_bf16(z, act_ptr(ctx, in), c.max_batch, c.unet_in_channels, c.latent_size, c.latent_size, in.ld, in.ld, 1,
-                                      1.f, s));
+  HIPCHK(launch_nchw_f32_to_nhwc_bf16(z, act_ptr(ctx, in), c.max_batch, c.unet_in_channels, c.latent_size, c.latent_size, in.ld, in.ld,
+                                      in.B == 2 * c.max_batch ? 1 : 0, 1.f, s));
   run_fwd(E->unet, ctx);
 }
 
@@ -1571,7 +1612,7 @@ void guided_backward(dd_engine* E, int k, int step_index, const float* g_znext, 
                              E->coef_table + (size_t)step_index * 8, s));
   run_bwd(E->unet, uc);
   const Tn& in = E->unet.t[E->unet_in];
-  HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, c.max_batch, c.unet_in_channels, HW, 1, s));
+  HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, c.max_batch, c.unet_in_channels, HW, 1, in.B == 2 * c.max_batch ? 2 : 1, s));
 }
 
 void set_config_defaults(dd_config& c) {
@@ -2166,7 +2207,7 @@ int dd_unet_vjp(dd_engine* E, const float* z, int step_index, const float* g_eps
                                         1.f, s));
     run_bwd(E->unet, uc);
     const Tn& in = E->unet.t[E->unet_in];
-    HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, B, c.unet_in_channels, HW, 0, s));
+    HIPCHK(launch_dup_bwd(grad_ptr(uc, in), in.ld, g_z_out, B, c.unet_in_channels, HW, 0, in.B == 2 * B ? 2 : 1, s));
   });
 }
 

@@ -146,8 +146,9 @@ hipError_t launch_cfg_ddim(const float* eps2, int ld, const float* z, float* z_p
 //   g_x0, g_zprev NCHW fp32 (either may be null) -> g_eps2 NHWC bf16 [2B*HW, ld] and g_z_direct NCHW fp32
 hipError_t launch_cfg_ddim_bwd(const float* g_x0, const float* g_zprev, bf16_t* g_eps2, int ld, float* g_z, int B, int C,
                                int HW, const float* coef_dev, hipStream_t s);
-// backward of cat[z, z] + NCHW->NHWC: g_z[b,c,pix] (+)= gin[b*HW+pix, c] + gin[(B+b)*HW+pix, c]
-hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, hipStream_t s);
+// backward of cat[z, z] + NCHW->NHWC: g_z[b,c,pix] (+)= gin[b*HW+pix, c] + gin[(B+b)*HW+pix, c]   (halves = 2), or of the plain
+// layout change when the UNet input itself is not duplicated (halves = 1: the two CFG halves share their prefix, engine.cpp)
+hipError_t launch_dup_bwd(const bf16_t* gin, int ld, float* g_z, int B, int C, int HW, int accumulate, int halves, hipStream_t s);
 // y = dy * (mask > 0)  (ReLU backward)
 hipError_t launch_mask_bf16(const bf16_t* dy, int ldd, const bf16_t* mask, int ldm, bf16_t* y, int ldy, int M, int C,
                             hipStream_t s);
