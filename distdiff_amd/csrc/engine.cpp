@@ -1528,11 +1528,11 @@ void vae_fwd(dd_engine* E, int k, const float* x0, hipStream_t s) {
 
 // features of a finished guide forward -> feats [B, D] fp32: global average pool of the last feature map (ResNets, model_utils.py:31-33)
 // or the projected class token (ViT)
-void guide_features_out(dd_engine* E, const Ctx& gc, float* feats, hipStream_t s) {
+void guide_features_out(dd_engine* E, const Ctx& gc, float* feats, hipStream_t s, int use_max = 0) {
   const dd_config& c = E->cfg;
   const Tn& f = E->guide.t[E->guide_feat];
   if (c.guide_kind == 1) HIPCHK(hipMemcpy2DAsync(feats, (size_t)f.C * 4, act_f32(gc, f), (size_t)f.ld * 4, (size_t)f.C * 4, f.rows, hipMemcpyDeviceToDevice, s));
-  else HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, feats, nullptr, c.max_batch, f.H * f.W, f.C, 0, s));
+  else HIPCHK(launch_gap_f32(act_f32(gc, f), f.ld, feats, nullptr, c.max_batch, f.H * f.W, f.C, use_max, s));
 }
 // cotangent of the features [B, D] fp32 -> gradient of the guide's output tensor (reverse of guide_features_out)
 void guide_features_grad_in(dd_engine* E, const Ctx& gc, const float* gfeat, hipStream_t s) {
@@ -2062,10 +2062,15 @@ int dd_text_encode(dd_engine* E, const int* input_ids, float* embeds_out, int n,
   });
 }
 
+int dd_guide_encode_pooled(dd_engine* E, const float* images, float* feats, int B, int use_max, void* stream);
 int dd_guide_encode(dd_engine* E, const float* images, float* feats, int B, void* stream) {
+  return dd_guide_encode_pooled(E, images, feats, B, 0, stream);
+}
+int dd_guide_encode_pooled(dd_engine* E, const float* images, float* feats, int B, int use_max, void* stream) {
   if (!E || !images || !feats) return DD_ERR_ARG;
   DD_TRY(E, {
     check_batch(E, B);
+    if (use_max && E->cfg.guide_kind == 1) throw std::runtime_error("the ViT guide has no spatial pooling (encode_image = the projected class token)");
     const dd_config& c = E->cfg;
     hipStream_t s = (hipStream_t)stream;
     Run r{E, s, B};
@@ -2073,7 +2078,7 @@ int dd_guide_encode(dd_engine* E, const float* images, float* feats, int B, void
     const Tn& gin = E->guide.t[E->guide_in];
     HIPCHK(launch_nchw_to_nhwc_f32(images, act_f32(gc, gin), B, 3, gin.H, gin.W, gin.ld, gin.ld, s));
     run_fwd(E->guide, gc);
-    guide_features_out(E, gc, feats, s);
+    guide_features_out(E, gc, feats, s, use_max);
   });
 }
 

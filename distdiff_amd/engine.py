@@ -73,6 +73,7 @@ def _declare(l):
     l.dd_decode.argtypes = [vp, vp, vp, i, i, vp]
     l.dd_expand.argtypes = [vp, C.POINTER(DDExpandArgs), vp]
     l.dd_guide_encode.argtypes = [vp, vp, vp, i, vp]
+    l.dd_guide_encode_pooled.argtypes = [vp, vp, vp, i, i, vp]
     l.dd_vae_encode.argtypes = [vp, vp, vp, vp, vp, i, vp]
     l.dd_text_encode.argtypes = [vp, vp, vp, i, vp]
     l.dd_image_to_u8.argtypes = [vp, vp, vp, i, vp]
@@ -334,10 +335,11 @@ class Engine:
         self._chk(self.L.dd_image_to_u8(self._h, _p(img), _p(out), img.shape[0], _stream()), "dd_image_to_u8")
         return out
 
-    def guide_encode(self, images):
+    def guide_encode(self, images, pooling="avg"):
+        """image_encoder.encode_image(x, pooling) (model_utils.py:29-41)."""
         x = self._f(images)
         f = torch.empty((x.shape[0], self.cfg.guide.feature_dim), device=self.device, dtype=torch.float32)
-        self._chk(self.L.dd_guide_encode(self._h, _p(x), _p(f), x.shape[0], _stream()), "dd_guide_encode")
+        self._chk(self.L.dd_guide_encode_pooled(self._h, _p(x), _p(f), x.shape[0], int(pooling == "max"), _stream()), "dd_guide_encode")
         return f
 
     def expand(self, image_latents, noise, e, b, targets, start_index, guidance_type, guide_first, guide_count, want_image=True):

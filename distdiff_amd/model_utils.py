@@ -50,9 +50,6 @@ class GuideModel:
     def encode_image(self, x, pooling="avg"):
         if pooling not in ("avg", "max"):
             raise ValueError("Unsupported pooling type. Please use 'avg' or 'max'.")      # model_utils.py:36-37
-        if pooling != "avg":
-            raise NotImplementedError("pooling='max' is not wired into the engine (the expansion path only ever uses the default "
-                                      "'avg', generate_data.py:705, :746; dataloader.py:676)")
         if self._engine is None:
             raise RuntimeError("GuideModel is not bound to an Engine (there is no CPU fallback): call .bind(engine)")
         B = self._engine.B
@@ -62,7 +59,7 @@ class GuideModel:
             n = xb.shape[0]
             if n < B:
                 xb = torch.cat([xb, xb[-1:].expand(B - n, -1, -1, -1)])
-            outs.append(self._engine.guide_encode(xb)[:n].clone())
+            outs.append(self._engine.guide_encode(xb, pooling)[:n].clone())
         return torch.cat(outs)
 
     def forward(self, x):

@@ -162,6 +162,9 @@ int dd_get_image_scores(dd_engine* e, float* scores_out, int B, void* stream);
 int dd_image_to_u8(dd_engine* e, const float* image, uint8_t* out_hwc, int B, void* stream);
 /* images: DEVICE fp32 [B,3,S,S] (S = guide_input_size) -> feats DEVICE fp32 [B, D] */
 int dd_guide_encode(dd_engine* e, const float* images, float* feats, int B, void* stream);
+/* encode_image(x, pooling='max') of model_utils.py:34-35 (AdaptiveMaxPool2d instead of the default average pool; forward only: the
+ * expansion path always uses 'avg', generate_data.py:705, :746) */
+int dd_guide_encode_pooled(dd_engine* e, const float* images, float* feats, int B, int use_max, void* stream);
 /* The stage before the loop; available when the state dicts carried vae/encoder.* + quant_conv.* and
  * text/text_model.* keys.  images: DEVICE fp32 [B,3,8L,8L] in [-1,1]; noise: DEVICE fp32 [B,4,L,L] ~ N(0,1) or NULL (the
  * distribution's mode); latents_out [B,4,L,L] already multiplied by scaling_factor; moments_out optional [B,8,L,L]

@@ -122,6 +122,8 @@ def test_guide_forward_and_vjp_vs_oracle(hip_lib, which):
     f_ref = guide.encode_image(xr)
     (g_ref,) = torch.autograd.grad(f_ref, xr, gf)
     assert rel(eng.guide_encode(x), f_ref.detach()) < 1e-4
+    with torch.no_grad():                                       # encode_image(x, pooling='max'), model_utils.py:34-35
+        assert rel(eng.guide_encode(x, pooling="max"), guide.encode_image(x, pooling="max")) < 1e-4
     # fp32 vs fp32: summation order only, plus a handful of activations within fp32 rounding of a ReLU / ReLU6 kink (measured 4e-7
     # on the ResNets, 2.7e-3 on the 53-layer two-sided-mask MobileNetV2)
     assert rel(eng.guide_vjp(x, gf), g_ref) < (5e-3 if cfg.guide.kind == "mbv2" else 2e-3)
