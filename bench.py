@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="images per step per GPU (train_batch_size)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="images per step per GPU; 0 = the largest of 32 / 16 / 8 whose workspace (7.6 GB per image at 512x512: two activation "
+                         "stashes for the chained guided steps) fits the free HBM of every rank")
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny", "sdxl"],
                     help="sd15 = BASELINE configs[1] (the metric's workload); sdxl = the SDXL-base UNet at 1024x1024 (configs[4] structure, bf16)")
     ap.add_argument("--guidance", default="transform_guidance", choices=["transform_guidance", "direct_guidance", "none"])
@@ -159,6 +161,16 @@ def main():
     from distdiff_amd.weights import synthetic_weights
 
     B = a.batch
+    if B <= 0:
+        if a.config == "sd15":
+            free = torch.cuda.mem_get_info(dev)[0]
+            B = 32 if free >= 262e9 else 16 if free >= 135e9 else 8     # measured: 243 / 122 / 65 GB of workspace + 4 GB of weights
+            if distributed and world > 1:
+                bmin = torch.tensor([B], device=dev, dtype=torch.int64)
+                dist.all_reduce(bmin, op=dist.ReduceOp.MIN)
+                B = int(bmin.item())
+        else:
+            B = 2 if a.config == "sdxl" else 16
     cfg = {"sd15": sd15_config, "tiny": tiny_config, "sdxl": sdxl_config}[a.config](max_batch=B)
     C_cls, K = 100, 3
     t_setup = time.time()
