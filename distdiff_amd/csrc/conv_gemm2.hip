@@ -21,7 +21,18 @@
 
 namespace {
 
-__device__ uint4 g_zero16[4];   // zero page for padded taps / ragged rows (device globals are zero-initialised)
+__device__ uint4 g_zero16[4];
+#ifdef DD_TRACE
+// debug build only (tools/conv_trace.py): s_memrealtime stamps (10 ns ticks) of the first and the last workgroup, thread 0
+__device__ unsigned long long g_trace[512];
+__device__ __forceinline__ void trace_stamp(int& n, int tag) {
+  const bool lastb = blockIdx.x == gridDim.x - 1;
+  if ((blockIdx.x == 0 || lastb) && threadIdx.x == 0 && n < 127) {
+    const int o = lastb ? 256 : 0;
+    g_trace[o + 2 * n] = __builtin_amdgcn_s_memrealtime(); g_trace[o + 2 * n + 1] = tag; ++n;
+  }
+}
+#endif   // zero page for padded taps / ragged rows (device globals are zero-initialised)
 
 // One 1 KB LDS-DMA piece: buffer_load_dwordx4 ... lds from base + voff (per lane) + soff (scalar); a lane whose voff is beyond the
 // 4 GB - 256 B range gets zeros written to its LDS slot (hardware range check) -- that is how padding taps and ragged rows are
@@ -69,6 +80,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
+#ifdef DD_TRACE
+  int tn = 0;
+  trace_stamp(tn, 3);
+#endif
 
   // ---- work list of this workgroup
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -518,6 +533,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   const bool issue_first = NW == 4 || wave < 4;       // 8 waves: SIMD partners run DMA issue and MFMAs in opposite order
   int cur = 0;
   bool drained = false;
+#ifdef DD_TRACE
+  trace_stamp(tn, 0);
+#endif
   // Every LDS read of the loop body is unconditional (the last K-step of the work list reads a stale stage into F0 and takes one
   // more barrier; `ahead` may go negative there, which only selects the vmcnt(0) form of the wait): a conditional ds_read makes the compiler's waitcnt pass fall back to lgkmcnt(0) at the join, which would
   // expose the F0 read latency in front of every MFMA(F1) block.
@@ -547,13 +565,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       prefetch_tap();
       cur = nxt;
     }
+#ifdef DD_TRACE
+    trace_stamp(tn, 1);
+#endif
     epilogue(cw);
+#ifdef DD_TRACE
+    trace_stamp(tn, 2);
+#endif
     drained = true;
     cw += Gx;
     if (cw >= w_end) break;
     c_left = min(ksteps, (cw % p.ksplit) * per + per) - (cw % p.ksplit) * per;
     zero_acc();
   }
+#ifdef DD_TRACE
+  trace_stamp(tn, 4);
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
@@ -597,6 +624,16 @@ hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef DD_TRACE
+extern "C" int dd_debug_clear_trace() {
+  static unsigned long long z[512];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z));
+}
+extern "C" int dd_debug_read_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 // tile choice for the big kernel: 0 = not applicable (use the 128x128 kernel), else config id
 int conv_gemm_big_config(int M, int N, int K, int flags) {
