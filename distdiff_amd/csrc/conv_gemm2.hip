@@ -73,6 +73,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   static_assert((NW == 8 || NW == 4) && BM % RPT == 0 && (BN % RPT == 0 || B_HALF) && (NS == 2 || NS == 3), "bad tile");
   constexpr int BUF_BYTES = (BM + BN) * 128;
   constexpr int DMA_PER_STAGE = AV + BV;
+  // bias of the n-tile of an item: one 1 KB LDS-DMA piece issued when the loader reaches the item (a ring of three: the loader is
+  // at most two items ahead of the epilogue), read from LDS by the batched epilogue -- a global load there costs an exposed L2 / HBM
+  // latency per item (tools/conv_trace.py: 3 us of epilogue on a 5-step item, half of it the bias wait)
+  constexpr int BIAS_OFF = NS * BUF_BYTES + 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -141,6 +145,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     __syncthreads();
   }
   const char* xbase = (const char*)p.x - tap_bias;
+  const float* bias = p.bias;
+  if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  int l_slot = 0, c_slot = 0;                 // bias ring slots of the loader's / the epilogue's item
   int lw = w_first, l_kt = 0, l_kend = 0;
   int l_tap = 0, l_chunk = 0, l_tb = 0;       // fast path: tap / chunk of K-step l_kt and its (prefetched) byte offset
   int pixb[AV], iy0[AV], ix0[AV];             // general path
@@ -171,6 +178,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     const int n0 = (tile % ntn) * BN;
     l_kt = kz * per;
     l_kend = min(ksteps, l_kt + per);
+    {
+      const int nb = n0 + lane * 4;
+      const unsigned voff = ((p.flags & CF_BIAS) && lane * 4 < BN && nb + 4 <= p.N) ? (unsigned)nb * 4u : OOB;
+      dma16(bias, smem + BIAS_OFF + l_slot * 1024, voff, 0);
+      l_slot = l_slot == 2 ? 0 : l_slot + 1;
+    }
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int m = m0 + r0 + RPT * i;
@@ -309,8 +322,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.wf[jn], F.xf[i], acc[jn][i], 0, 0, 0);
   };
-  const float* bias = p.bias;
-  if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
   // CF_STATS: per-(64-row block, channel) partial statistics of the values this wave stores, for the GroupNorm that consumes the
   // tensor: s1 / s2 hold this lane's sums over its 4 pixel rows, the 16 lanes of an MFMA row are summed with 4 DPP adds per value,
   // lane fr == 0 stores (mean, M2) of its 4 channels.  ~8 * TN * 4 VALU per wave and work item.
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       const int wb = n0 + wn * (TN * 16);
       float4 bv[TN];
 #pragma unroll
-      for (int jn = 0; jn < TN; ++jn) bv[jn] = (fl & CF_BIAS) ? *(const float4*)(bias + wb + col_of(jn)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int jn = 0; jn < TN; ++jn) bv[jn] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (wn * (TN * 16) + col_of(jn)) * 4);
       const int cp = wb + fq * 8, co = wb + (TN - 1) * 16 + fq * 4;       // pair t: cp + 32 t ; odd last tile: co
       uint4 rvp[TM][TN / 2];
       uint2 rvo[TM];
@@ -426,8 +437,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
         float4 bh[TN / 2], bg[TN / 2];
 #pragma unroll
         for (int t = 0; t < TN / 2; ++t) {
-          bh[t] = (fl & CF_BIAS) ? *(const float4*)(bias + ncol0 + 2 * t * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-          bg[t] = (fl & CF_BIAS) ? *(const float4*)(bias + ncol0 + 2 * t * 16 + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+          bh[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
+          bg[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -569,6 +580,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     trace_stamp(tn, 1);
 #endif
     epilogue(cw);
+    c_slot = c_slot == 2 ? 0 : c_slot + 1;
 #ifdef DD_TRACE
     trace_stamp(tn, 2);
 #endif
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
 hipError_t run_big_fe3(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = NS * (BM + BN) * 128 + 256;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets)
+  constexpr int lds = NS * (BM + BN) * 128 + 256 + 3 * 1024;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets)
   static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -611,13 +623,14 @@ hipError_t run_big_fe(const ConvGemmParams& p, hipStream_t stream) {
 }
 template <int WM, int WN, int TM, int TN, int NS>
 hipError_t run_big(const ConvGemmParams& p, hipStream_t stream) {
-  // Two instantiations per tile.  The batched epilogue (FE: bias and all residual loads issued together, 16-byte stores)
-  // saves ~15 us per work item over the generic one, but its instantiation runs the K loop ~0.18 us per K-step slower on
-  // L2-resident operands (register allocation; same loop source, same instruction mix).  Break-even ~80-100 K-steps per item,
-  // measured on the same device with tools/ab_ops.sh: FE always -> 1162 ms of conv per bench step, FE <= 100 steps -> 1146 ms.
+  // Two instantiations per tile.  The batched epilogue (FE: bias from the LDS ring, all residual loads issued together, 16-byte
+  // stores) saves ~15 us per work item over the generic one; its instantiation used to run the K loop ~0.18 us per K-step slower
+  // (register allocation), which made the generic form the better one beyond ~100 K-steps per item.  With the bias staged through
+  // LDS the batched form wins at every depth (same-device tools/ab_ops.sh, 32-image batch: limit 60 -> 1975 ms of conv, 100 -> 1949,
+  // none -> 1936), so only split-K items (fp32 partial stores, no epilogue work) take the generic instantiation.
   const int steps_per_item = (p.K / 64 + p.ksplit - 1) / p.ksplit;
 #ifndef DD_FE_LIMIT
-#define DD_FE_LIMIT 100
+#define DD_FE_LIMIT 1000000
 #endif
   // split-K items only store fp32 partials (same code in both instantiations): take the faster loop
   return (steps_per_item <= DD_FE_LIMIT && p.ksplit == 1) ? run_big_fe<WM, WN, TM, TN, NS, true>(p, stream) : run_big_fe<WM, WN, TM, TN, NS, false>(p, stream);
