@@ -170,7 +170,7 @@ def main():
                 dist.all_reduce(bmin, op=dist.ReduceOp.MIN)
                 B = int(bmin.item())
         else:
-            B = 2 if a.config == "sdxl" else 16
+            B = (4 if torch.cuda.mem_get_info(dev)[0] >= 175e9 else 2) if a.config == "sdxl" else 16     # sdxl: 161 / 115 GB; 6 is no faster
     cfg = {"sd15": sd15_config, "tiny": tiny_config, "sdxl": sdxl_config}[a.config](max_batch=B)
     C_cls, K = 100, 3
     t_setup = time.time()
