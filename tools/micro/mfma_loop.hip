@@ -48,10 +48,12 @@ __global__ __launch_bounds__(512) void k(const unsigned char* src, float* out, i
       if (MODE & 16) {
         const int tap = s % 9, chunk = (s / 9) % 5;
         const long toff = ((tap / 3 - 1) * 64 + (tap % 3 - 1)) * 640 + chunk * 128;
+        if (!(MODE & 32))   // bit 5: no A pieces (what a halo slab reused by the nine taps would leave: ~0.6 of 4 per K-step)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc2 + toff + (size_t)(i * 64 + wave * 8) * 640),
                                            (__attribute__((address_space(3))) void*)(smem + ((cur + 2) % 3) * BUF + (i * 8 + wave) * 1024), 16, 0, 0);
+        if (!(MODE & 64))   // bit 6: no weight pieces
 #pragma unroll
         for (int i = 4; i < 7; ++i)   // weights: rows of 128 B at a 5760 B stride, shared by all blocks
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (48u << 20) + (size_t)(((i - 4) * 64 + wave * 8 + (lane >> 3)) * 5760 + (s % 45) * 128 + (lane & 7) * 16)),
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512) void k(const unsigned char* src, float* out, i
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) acc[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[i], acc[jn][i], 0, 0, 0);
     }
-    if (MODE & 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if (MODE & 4) { if (MODE & 32) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else if (MODE & 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
     if (MODE & 2) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     cur = cur == 2 ? 0 : cur + 1;
   }
@@ -236,6 +238,8 @@ int main() {
   run<8 + 7>(src, out, steps, "all, random data");
   run<16 + 8 + 7>(src, out, steps, "all, random, conv gather pattern");
   run<16 + 8 + 4>(src, out, steps, "mfma + dma gather, random");
+  run<32 + 16 + 8 + 7>(src, out, steps, "all, conv gather, weight pieces only (3)");
+  run<64 + 16 + 8 + 7>(src, out, steps, "all, conv gather, A pieces only (4)");
   run2<1, 0>(src, out, steps, "swp structure, stagger");
   run2<0, 1>(src, out, steps, "swp structure, dma before mma");
   run2<0, 0>(src, out, steps, "swp structure, dma after mma");
