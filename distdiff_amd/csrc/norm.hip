@@ -304,6 +304,72 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p,
   }
 }
 
+// ---------------- LayerNorm forward, narrow rows (C <= 1536): a wave takes LN_RPW consecutive rows, all their loads in flight at
+// once (a 320-channel row is only 640 bytes: one row per wave left the kernel latency-bound), gamma / beta in registers ------------
+constexpr int LN_RPW = 4;
+template <int VI>
+__global__ __launch_bounds__(256) void ln_rows_kernel(LayerNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+  if (row0 >= p.M) return;
+  const int VC = p.C >> 3;
+  float ga[VI][8], be[VI][8];
+#pragma unroll
+  for (int i = 0; i < VI; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < VC) {
+      const float4 g0 = *(const float4*)(p.gamma + vc * 8), g1 = *(const float4*)(p.gamma + vc * 8 + 4);
+      const float4 b0 = *(const float4*)(p.beta + vc * 8), b1 = *(const float4*)(p.beta + vc * 8 + 4);
+      ga[i][0] = g0.x; ga[i][1] = g0.y; ga[i][2] = g0.z; ga[i][3] = g0.w; ga[i][4] = g1.x; ga[i][5] = g1.y; ga[i][6] = g1.z; ga[i][7] = g1.w;
+      be[i][0] = b0.x; be[i][1] = b0.y; be[i][2] = b0.z; be[i][3] = b0.w; be[i][4] = b1.x; be[i][5] = b1.y; be[i][6] = b1.z; be[i][7] = b1.w;
+    }
+  }
+  uint4 raw[LN_RPW][VI];
+#pragma unroll
+  for (int r = 0; r < LN_RPW; ++r)
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int vc = lane + 64 * i;
+      raw[r][i] = make_uint4(0, 0, 0, 0);
+      if (vc < VC && row0 + r < p.M) raw[r][i] = *(const uint4*)(p.x + (size_t)(row0 + r) * p.x_ld + vc * 8);
+    }
+#pragma unroll
+  for (int r = 0; r < LN_RPW; ++r) {
+    const int row = row0 + r;
+    if (row >= p.M) break;                    // wave-uniform
+    float xv[VI][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      unpack8(raw[r][i], xv[i]);
+      if (lane + 64 * i < VC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xv[i][e];
+      }
+    }
+    const float mean = wave_sum(s) / p.C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < VI; ++i)
+      if (lane + 64 * i < VC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; v += d * d; }
+      }
+    const float rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
+    if (lane == 0 && p.stats) { p.stats[(size_t)row * 2] = mean; p.stats[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < VC) {
+        float ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (xv[i][e] - mean) * rstd * ga[i][e] + be[i][e];
+        *(uint4*)(p.y + (size_t)row * p.y_ld + vc * 8) = pack8(ov);
+      }
+    }
+  }
+}
+
 // ---------------- LayerNorm: one wave per row, up to 4 x 64 x 8 = 2048 channels ----------------
 template <bool BWD>
 __global__ __launch_bounds__(256) void ln_kernel(LayerNormParams p) {
@@ -438,6 +504,17 @@ hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream) {
 
 hipError_t launch_layernorm_fwd(const LayerNormParams& p, hipStream_t stream) {
   if (p.C % 8 || p.C > 2048 || (p.x_ld & 7) || (p.y_ld & 7)) return hipErrorInvalidValue;
+  static const int rows_kernel = getenv("DD_LN_ROWS") ? atoi(getenv("DD_LN_ROWS")) : 1;   // A/B switch
+  if (rows_kernel && p.C <= 1536) {
+    const int vi = (p.C / 8 + 63) / 64;
+    const int blocks = (p.M + 4 * LN_RPW - 1) / (4 * LN_RPW);
+    switch (vi) {
+      case 1: hipLaunchKernelGGL((ln_rows_kernel<1>), dim3(blocks), dim3(256), 0, stream, p); break;
+      case 2: hipLaunchKernelGGL((ln_rows_kernel<2>), dim3(blocks), dim3(256), 0, stream, p); break;
+      default: hipLaunchKernelGGL((ln_rows_kernel<3>), dim3(blocks), dim3(256), 0, stream, p); break;
+    }
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((ln_kernel<false>), dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
   return hipGetLastError();
 }

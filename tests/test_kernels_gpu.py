@@ -187,7 +187,7 @@ def test_groupnorm(ops, Cc, G, HW, silu, eps):
     assert_close(dx.float().cpu().reshape(B, HW, Cc).permute(0, 2, 1), gx, rtol=2e-2, atol=2e-3, what="gn bwd")
 
 
-@pytest.mark.parametrize("Cc", [320, 1280, 64])
+@pytest.mark.parametrize("Cc", [320, 640, 1280, 64, 2048])     # 1-3 vectors per lane (multi-row kernel), one-row kernel beyond 1536
 def test_layernorm(ops, Cc):
     g = torch.Generator().manual_seed(6)
     M = 77
