@@ -122,3 +122,12 @@ def test_image_transform_matches_reference_pipeline(tmp_path):
     g2 = load_image(str(tmp_path / "g.png"), 64, rng=np.random.RandomState(3))
     assert g1.shape == (3, 64, 64) and torch.equal(g1, g2) and torch.equal(g1[0], g1[1])
     assert CUSTOM_TEMPLATES["caltech-101"].format("sea horse") == "a photo of a sea horse."
+
+
+def test_auto_engine_batch_without_a_gpu():
+    """--engine_batch 0: 8 for --tiny, 16 when there is no device to size the batch for (the HBM-sized choice needs a GPU)."""
+    from distdiff_amd.generate_data import auto_engine_batch, parse_args
+    a = parse_args(["--synthetic", "4", "--tiny"])
+    assert auto_engine_batch(a, "cpu") == 8
+    a = parse_args(["--synthetic", "4"])
+    assert auto_engine_batch(a, "cpu") == 16
