@@ -123,15 +123,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   // the per-tap offset table lives in LDS: a global load inside the pipeline would force s_waitcnt vmcnt(0)
   // (vmcnt retires in order) and drain the in-flight DMA stages
   int* taps = (int*)(smem + NS * BUF_BYTES);
-  for (int t = tid; t < p.ntaps; t += NT) taps[t] = p.taptab[t];
-  __syncthreads();
+  // 1x1 / linear layers (one tap, same-size output: the packers give them the centre tap): no tap table at all -- its global load
+  // is an HBM-latency wait plus three barriers in front of the first DMA of every workgroup, and these are the short kernels
+  const bool pointwise = fast && p.ntaps == 1 && p.stride == 1 && p.H == p.Ho && p.W == p.Wo;
+  if (!pointwise) {
+    for (int t = tid; t < p.ntaps; t += NT) taps[t] = p.taptab[t];
+    __syncthreads();
+  }
   // Fast path staging uses buffer_load ... lds: the per-lane byte offset of a row is fixed for a whole work item, the K-step
   // (tap, 64-channel chunk) moves through the scalar offset, and an out-of-range offset makes the hardware write zeros
   // (padding taps, ragged rows) -- 3 VALU per 1 KB piece instead of a 64-bit address select.  The base is moved back by the most
   // negative tap offset so that the scalar offset stays unsigned.
   constexpr unsigned OOB = 0xfffffff0u;
   int tap_bias = 0;
-  if (fast) {
+  if (fast && !pointwise) {
     for (int t = 0; t < p.ntaps; ++t) {
       const int e = taps[t];
       tap_bias = max(tap_bias, -((((e >> 6) & 63) - 32) * p.W + ((e & 63) - 32)) * p.x_ld * 2);
@@ -158,10 +163,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   // the epilogue moves 16 bytes per lane (4 lanes = 64 contiguous bytes per pixel) instead of 8.  An odd last tile keeps the plain
   // layout; GEGLU has its own (hidden | gate) pairing.  The permutation costs nothing: it only changes which weight row a DMA
   // lane fetches.
-  // (read through readfirstlane: a value loaded from LDS is "divergent" to the compiler, and a divergent `pointwise` would push the
-  //  tap / chunk counters into VGPRs and turn every buffer_load's scalar offset into a waterfall loop)
-  const bool pointwise = fast && p.ntaps == 1 && p.stride == 1 && p.H == p.Ho && p.W == p.Wo &&
-                         __builtin_amdgcn_readfirstlane(taps[0]) == ((32 << 6) | 32);
   const bool pair_cols = !(p.flags & CF_GEGLU);
   constexpr int TNP = TN & ~1;
   auto chan_of_row = [&](int R) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     }
   };
   // byte offset of the loader's tap, read one K-step before issue_step consumes it (unconditional: see the note on the peeled step)
-  auto prefetch_tap = [&]() { if (fast) l_tb = taps[32 + l_tap]; };
+  auto prefetch_tap = [&]() { if (fast && !pointwise) l_tb = taps[32 + l_tap]; };
   auto issue_step = [&](int buf) {   // enqueue the LDS-DMA of K-step l_kt of the loader's item into buffer `buf`
     const int kt = l_kt;
 
