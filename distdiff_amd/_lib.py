@@ -89,12 +89,13 @@ OPS_SYMBOLS = [
     "dd_pack_conv_weight", "dd_op_conv_f32", "dd_pack_conv_weight_f32", "dd_op_nchw_f32_to_nhwc_bf16", "dd_op_nhwc_to_nchw_f32", "dd_op_cfg_ddim",
     "dd_op_cfg_ddim_bwd", "dd_op_sumpool2x2", "dd_op_geglu_bwd", "dd_op_maxpool3x3s2", "dd_op_maxpool3x3s2_bwd",
     "dd_op_bicubic", "dd_op_bicubic_bwd", "dd_op_gap", "dd_op_energy", "dd_op_transform_update", "dd_op_affine",
+    "dd_debug_tensor", "dd_debug_num_tensors", "dd_debug_set_image", "dd_debug_set_images",
 ]
 ENGINE_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
     "dd_set_schedule", "dd_add_noise", "dd_denoise_step", "dd_transform_guidance", "dd_direct_guidance", "dd_decode",
     "dd_expand", "dd_image_to_u8", "dd_guide_encode", "dd_guide_encode_pooled", "dd_unet_forward", "dd_unet_vjp", "dd_decode_vjp", "dd_guide_vjp",
-    "dd_set_prompt", "dd_set_added_cond", "dd_vae_encode", "dd_text_encode", "dd_set_sample_weights", "dd_get_image_scores", "dd_declare_tensor", "dd_packed_bytes", "dd_export_packed", "dd_import_packed", "dd_debug_tensor", "dd_debug_num_tensors", "dd_debug_set_image", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
+    "dd_set_prompt", "dd_set_added_cond", "dd_vae_encode", "dd_text_encode", "dd_set_sample_weights", "dd_get_image_scores", "dd_declare_tensor", "dd_packed_bytes", "dd_export_packed", "dd_import_packed", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
 ]
 
 

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/distdiff_hip.h"
+#include "../../include/distdiff_hip_ops.h"
 #include "kernels.h"
 
 namespace {
@@ -265,7 +266,7 @@ struct dd_engine {
   float* score_tmp = nullptr;
   float* sample_w = nullptr; bool sample_w_set = false;   // per-image energy weights (dd_set_sample_weights); default 1/B
   float* image_scores = nullptr;                         // per-image energies of the last guidance call
-  const float* image_override = nullptr;                 // dd_debug_set_image: parity tests evaluate the guide at a given image
+  const float* image_override = nullptr; int image_override_count = 0;   // dd_debug_set_images: parity tests evaluate the guide at given images
   size_t total_bytes = 0;
   double flops = 0;
   Profiler prof;
@@ -1555,8 +1556,11 @@ void guide_fwd_from_image(dd_engine* E, int k, hipStream_t s) {
   const Tn& img = E->vae.t[E->vae_out];
   const Tn& gin = E->guide.t[E->guide_in];
   // the decoder's conv_out stores the image in fp32: image, bicubic resize and the whole guide stay fp32
-  if (E->image_override)   // parity tests: the guide (its ReLU / max-pool masks) is evaluated AT the given image, gradients flow as usual
-    HIPCHK(launch_nchw_to_nhwc_f32(E->image_override, act_f32(vc, img), c.max_batch, c.vae_out_channels, img.H, img.W, img.ld, img.ld, s));
+  if (E->image_override) {  // parity tests: the guide (its ReLU / max-pool masks) is evaluated AT the given image, gradients flow as usual
+    const size_t per = (size_t)c.max_batch * c.vae_out_channels * img.H * img.W;
+    const float* src = E->image_override + per * std::min(k, E->image_override_count - 1);
+    HIPCHK(launch_nchw_to_nhwc_f32(src, act_f32(vc, img), c.max_batch, c.vae_out_channels, img.H, img.W, img.ld, img.ld, s));
+  }
   HIPCHK(launch_bicubic_f32(act_f32(vc, img), img.ld, act_f32(gc, gin), gin.ld, c.max_batch, img.H, img.W, gin.H, gin.W, 3, gin.ld, s));
   run_fwd(E->guide, gc);
   guide_features_out(E, gc, E->inst[k].feat, s);
@@ -2308,11 +2312,13 @@ int dd_debug_tensor(dd_engine* E, int prog_inst, int idx, int want_grad, float* 
 }
 // parity-test hook: image DEVICE fp32 [B,3,8L,8L] (not denormalised) replaces the decoder's output in front of the bicubic resize of
 // every later guided forward (the gradient still flows through the decoder); NULL switches it off.  The caller keeps the buffer alive.
-int dd_debug_set_image(dd_engine* E, const float* image) {
-  if (!E) return DD_ERR_ARG;
-  E->image_override = image;
+int dd_debug_set_images(dd_engine* E, const float* images, int count) {
+  if (!E || count < 0) return DD_ERR_ARG;
+  E->image_override = count > 0 ? images : nullptr;
+  E->image_override_count = E->image_override ? count : 0;
   return DD_OK;
 }
+int dd_debug_set_image(dd_engine* E, const float* image) { return dd_debug_set_images(E, image, 1); }
 int dd_debug_num_tensors(dd_engine* E, int prog) {
   if (!E || prog < 0 || prog > 2) return DD_ERR_ARG;
   return (int)(prog == 0 ? E->unet : prog == 1 ? E->vae : E->guide).t.size();

@@ -4,7 +4,17 @@
 
 #define S(x) ((hipStream_t)(x))
 extern "C" {
-int dd_op_conv_gemm(const ConvGemmParams* p, size_t cap, void* st) { return (int)launch_conv_gemm(*p, cap, S(st)); }
+int dd_op_conv_gemm(const ConvGemmParams* p, size_t cap, void* st) {
+  // One-tap, stride-1, same-size launches take the persistent kernel's pointwise path, which does not read the tap table: it IS the
+  // centre tap (what every packer emits for 1x1 / linear layers).  A caller-supplied table with another single tap is rejected here
+  // (this diagnostic entry point may synchronise; the engine's own launches come from the packers).
+  if (p->ntaps == 1 && p->stride == 1 && p->H == p->Ho && p->W == p->Wo && p->shift == 0 && p->taptab) {
+    int tap = 0;
+    if (hipMemcpy(&tap, p->taptab, sizeof tap, hipMemcpyDeviceToHost) != hipSuccess) return (int)hipErrorInvalidValue;
+    if (tap != ((32 << 6) | 32)) return (int)hipErrorInvalidValue;
+  }
+  return (int)launch_conv_gemm(*p, cap, S(st));
+}
 int dd_op_groupnorm_fwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_fwd(*p, S(st)); }
 int dd_op_groupnorm_bwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_bwd(*p, S(st)); }
 size_t dd_op_groupnorm_scratch_bytes(int B, int G) { return groupnorm_scratch_bytes(B, G); }

@@ -88,6 +88,7 @@ def _declare(l):
     l.dd_debug_tensor.argtypes = [vp, i, i, i, vp, vp]
     l.dd_debug_num_tensors.argtypes = [vp, i]
     l.dd_debug_set_image.argtypes = [vp, vp]
+    l.dd_debug_set_images.argtypes = [vp, vp, i]
     l.dd_workspace_bytes.argtypes = [vp]
     l.dd_workspace_bytes.restype = C.c_size_t
     l.dd_flops_last.argtypes = [vp]
@@ -406,9 +407,11 @@ class Engine:
         return self.debug_tensor(1, -1, instance=instance).reshape(self.B, L8, L8, 3).permute(0, 3, 1, 2).contiguous()
 
     def set_guide_image(self, image):
-        """Parity-test hook (dd_debug_set_image): evaluate the guide of later guided forwards at `image` [B,3,8L,8L]; None = off."""
+        """Parity-test hook (dd_debug_set_images): evaluate the guide of later guided forwards at `image` -- [B,3,8L,8L] for every
+        chained step, or [P,B,3,8L,8L] with one image set per chained guided step; None = off."""
         self._override = self._f(image) if image is not None else None
-        self._chk(self.L.dd_debug_set_image(self._h, _p(self._override)), "dd_debug_set_image")
+        count = 0 if image is None else (self._override.shape[0] if self._override.dim() == 5 else 1)
+        self._chk(self.L.dd_debug_set_images(self._h, _p(self._override), count), "dd_debug_set_images")
 
     def debug_num_tensors(self, prog):
         return int(self.L.dd_debug_num_tensors(self._h, prog))

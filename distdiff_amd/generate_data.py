@@ -193,7 +193,8 @@ class AsyncPNGWriter:
     """Output stage: quantise on the GPU, copy device->pinned host asynchronously, encode PNGs on a thread
     pool, so the next batch's kernels are enqueued while the previous batch is read back and encoded."""
 
-    def __init__(self, engine, writer=save_png, threads=4):
+    def __init__(self, engine, writer=save_png, threads=None):
+        threads = threads or int(os.environ.get("DD_PNG_THREADS", "4"))    # the launcher caps it by cpu_count // ranks
         from concurrent.futures import ThreadPoolExecutor
         self.engine, self.writer = engine, writer
         self.pool = ThreadPoolExecutor(max_workers=threads)
@@ -263,7 +264,14 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
     EB = engine.B
     transform = args.guidance_type == "transform_guidance"
     noise_gen = torch.Generator(device=rng_device)
-    noise_gen.manual_seed(int(args.seed or 0))
+    if args.seed is None:
+        # no seed (programmatic callers; the CLI's default is the reference's 42, generate_data.py:370): fresh noise per run, like the
+        # reference's unseeded global generator, and logged so that the run can be repeated
+        log.info("initial-noise generator seed: %d", noise_gen.seed())
+    else:
+        # the reference seeds its global generators once per process with --seed (set_seed, :859-861), so every invocation -- a resumed
+        # run, a later --first_image_index -- replays the same noise stream from its first unit; kept as is
+        noise_gen.manual_seed(int(args.seed))
     Cl = ds.latents.shape[1]
     units = []      # (dataset index, path, group id, group size, e[4], b[4], prompt embedding, noise offset[C] or None)
     n_groups = 0
@@ -418,19 +426,24 @@ def main(argv=None):
         raise SystemExit("guide arch %r is not built (built: %s; SURVEY.md section 8f-4)" % (args.arch, ", ".join(SUPPORTED)))
     if args.gpus > 1 and "RANK" not in os.environ:
         # the in-process fan-out that replaces single_exp.sh / expand_diff.sh's one shell per GPU: start the ranks before any GPU call
-        from .launcher import spawn_ranks
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU in this (parent) process
-        if have < args.gpus:
+        from .launcher import spawn_ranks, visible_gpu_count
+        have = visible_gpu_count()                # sysfs / visibility variables: the parent never loads the HIP runtime
+        if 0 < have < args.gpus:
             raise SystemExit("--gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
         return spawn_ranks(args.gpus, argv)
     distributed = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank, world, device = 0, 1, None
     if distributed:
         from .launcher import init_distributed
-        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        if lr >= torch.cuda.device_count():
+            raise SystemExit("rank %s: LOCAL_RANK %d but only %d GPU(s) are visible" % (os.environ.get("RANK"), lr, torch.cuda.device_count()))
+        device = "cuda:%d" % lr
         torch.cuda.set_device(torch.device(device))
         rank, world = init_distributed(device)
         args.split, args.total_split = rank, world          # the reference's --split / --total_split, one per rank
+    if os.environ.get("OMP_NUM_THREADS"):
+        torch.set_num_threads(max(1, int(os.environ["OMP_NUM_THREADS"])))       # the launcher's per-rank share of the host cores
     if args.seed is not None:
         import random
         import numpy as np

@@ -38,21 +38,90 @@ def _free_port():
     return port
 
 
-def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None):
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT loading the HIP / HSA runtime (the launcher parent must stay GPU-free: it forks the ranks,
+    and `torch.cuda.device_count()` falls back to hipGetDeviceCount -- i.e. initialises the runtime -- whenever amdsmi is not
+    usable).  The visibility variables win (the first one set, in the runtime's order of precedence); otherwise the KFD topology is
+    read from sysfs: a node with simd_count > 0 is a GPU."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""]) if v.strip() not in ("", "-1") else 0
+    return kfd_gpu_count()
+
+
+def kfd_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
+    n = 0
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, node, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
+def rank_thread_env(n):
+    """Host threads of one rank: N ranks share the node's cores (PNG encoding, torch's intra-op pool), so each gets cpu_count // N
+    instead of every rank spawning a pool sized for the whole machine."""
+    per = max(1, (os.cpu_count() or 1) // max(1, n))
+    return {"OMP_NUM_THREADS": str(per), "MKL_NUM_THREADS": str(per), "DD_PNG_THREADS": str(max(1, min(4, per)))}
+
+
+def exit_code(rc):
+    """Popen return code -> shell exit code: a rank killed by signal N (Popen reports -N: SIGSEGV, the NCCL watchdog's SIGABRT, an
+    OOM SIGKILL) becomes 128 + N, never 0."""
+    return 128 - rc if rc < 0 else rc
+
+
+def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None, grace=10.0, poll=0.2):
     """Starts `n` worker processes of the CLI (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
-    127.0.0.1) and waits for them; returns the largest exit code.  The parent never touches the GPU."""
+    127.0.0.1) and supervises them: all children are polled together; as soon as one exits non-zero (signals included) the others
+    -- which would otherwise sit in a collective until the RCCL timeout -- are terminated (SIGTERM, SIGKILL after `grace`
+    seconds) and its code is returned (128 + N for signal N).  Returns 0 only if every rank returned 0.  The parent never
+    touches the GPU."""
     port = _free_port()
     procs = []
+    threads = rank_thread_env(n)
     for r in range(n):
         env = dict(os.environ)
+        for k, v in threads.items():
+            env.setdefault(k, v)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, "-m", module] + list(argv), env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, p.wait())
-    return rc
+    failed = 0
+    live = list(procs)
+    try:
+        while live and not failed:
+            time.sleep(poll)
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and not failed:
+                    failed = exit_code(rc)
+                    print("[launcher] rank %d exited with %s: stopping the other ranks" % (procs.index(p), ("signal %d" % -rc) if rc < 0 else "code %d" % rc),
+                          file=sys.stderr, flush=True)
+    finally:
+        if live:            # a failed sibling, or the parent itself is going down (KeyboardInterrupt): no orphans
+            for p in live:
+                p.terminate()
+            deadline = time.time() + grace
+            for p in live:
+                try:
+                    p.wait(max(0.0, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    return failed
 
 
 def init_distributed(device=None):
@@ -62,11 +131,15 @@ def init_distributed(device=None):
     if "RANK" not in os.environ:
         return 0, 1
     if not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the other ranks wait in a barrier while rank 0 lists the dataset, VAE-encodes the latent cache and runs the text encoder
+        # (generate_data.main): the default collective timeout of 10 minutes is too short for a first run on a large dataset
+        timeout = datetime.timedelta(seconds=float(os.environ.get("DD_DIST_TIMEOUT_S", 4 * 3600)))
         if device is not None and torch.device(device).type == "cuda":
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.init_process_group("nccl", device_id=torch.device(device), timeout=timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timeout)
     return dist.get_rank(), dist.get_world_size()
 
 

@@ -10,6 +10,17 @@ def _step_index(engine, t):
     return engine.timesteps.index(int(t))
 
 
+def _prototypes(engine, total_global_proto, total_local_proto):
+    """The reference passes the prototype tables with every call (:1204-1213); the engine keeps them on the device, so they are
+    uploaded when the caller hands over different tensors than last time (None, None = keep what dd_set_prototypes installed)."""
+    if total_global_proto is None and total_local_proto is None:
+        return
+    key = (id(total_global_proto), id(total_local_proto))
+    if getattr(engine, "_shim_proto_key", None) != key:
+        engine.set_prototypes(total_global_proto, total_local_proto)
+        engine._shim_proto_key = key
+
+
 def denoise_one_step(latents, noise_scheduler, t, unet, prompt_embeds, class_labels):
     """-> (latents, x_0). `unet` is the Engine; prompt_embeds = cat[negative, prompt] is installed with engine.set_prompt."""
     engine = unet
@@ -27,6 +38,7 @@ def transform_guidance(latents, batch, sub_timesteps, noise_scheduler, unet, pro
     channel_noise_bias = torch.zeros([bs, ch, 1, 1]).normal_(0, 1)              # :694
     if prompt_embeds is not None:
         engine.set_prompt(prompt_embeds)
+    _prototypes(engine, total_global_proto, total_local_proto)
     first = _step_index(engine, sub_timesteps[0])
     z, score, _ = engine.transform_guidance(latents, batch["targets"], channel_noise, channel_noise_bias, first, len(sub_timesteps))
     return z, score[0]
@@ -38,5 +50,6 @@ def direct_guidance(latents, batch, t_i, noise_scheduler, unet, prompt_embeds, c
     engine = unet
     if prompt_embeds is not None:
         engine.set_prompt(prompt_embeds)
+    _prototypes(engine, total_global_proto, total_local_proto)
     zn, x0, score, _ = engine.direct_guidance(latents, batch["targets"], _step_index(engine, t_i))
     return zn, x0, score[0]

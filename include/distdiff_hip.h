@@ -187,15 +187,7 @@ int dd_guide_vjp(dd_engine* e, const float* images, const float* g_feats, float*
 int dd_profile_enable(dd_engine* e, int on);
 int dd_profile_read(dd_engine* e, double* out12);
 
-/* debug introspection of the op graph: host copy of an activation or gradient of tensor idx (negative: from the end, -1 = the
- * program's output) of program (prog & 15) = 0 unet / 1 vae / 2 guide, chained-step instance (prog >> 4) */
-int dd_debug_tensor(dd_engine* e, int prog, int idx, int want_grad, float* host_out, int* info4);
-int dd_debug_num_tensors(dd_engine* e, int prog);
-/* parity-test hook: evaluate the guide network of every later guided forward AT this image (DEVICE fp32 [B,3,8L,8L], the decoder's
- * output range, caller-owned) instead of the decoder's own output; gradients still flow through the decoder.  The input-gradient of the
- * ReLU / max-pool guide is piecewise constant in the image, so two implementations of torch.autograd.grad(E, ...) (generate_data.py:721,
- * :761) can only be compared at the same image.  NULL switches it off. */
-int dd_debug_set_image(dd_engine* e, const float* image);
+/* test-only introspection hooks (dd_debug_*) live in include/distdiff_hip_ops.h */
 
 size_t dd_workspace_bytes(dd_engine* e);
 /* algorithmic MFMA-eligible FLOPs (conv/linear/attention, 2 per MAC) enqueued since the last call */

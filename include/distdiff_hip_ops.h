@@ -33,6 +33,9 @@ struct LayerNormParams;
 struct AttnParams;
 struct ConvF32Params;
 
+/* taptab contract: entry t = ((dy + 32) << 6) | (dx + 32).  A launch with ONE tap, stride 1 and an output of the input's size is a
+ * pointwise (1x1 / linear) layer and must carry the centre tap (dy = dx = 0) -- the persistent kernel skips the table for it; any
+ * other single tap is rejected with hipErrorInvalidValue. */
 int dd_op_conv_gemm(const struct ConvGemmParams* p, size_t partial_cap_bytes, void* stream);
 int dd_op_groupnorm_fwd(const struct GroupNormParams* p, void* stream);
 int dd_op_groupnorm_bwd(const struct GroupNormParams* p, void* stream);
@@ -82,6 +85,20 @@ int dd_op_energy(const float* f, const float* Pc, const float* Pg, const int* ta
 int dd_op_transform_update(const float* z, const float* g, const float* e, const float* b, float* z_out, int BC, int HW,
                            float rho, float c, void* stream);
 int dd_op_affine(const float* z, const float* e, const float* b, float* out, int BC, int HW, void* stream);
+
+/* ---- test-only hooks into a dd_engine (include/distdiff_hip.h); no production caller ----
+ * debug introspection of the op graph: host copy of an activation or gradient of tensor idx (negative: from the end, -1 = the
+ * program's output) of program (prog & 15) = 0 unet / 1 vae / 2 guide, chained-step instance (prog >> 4) */
+struct dd_engine;
+int dd_debug_tensor(struct dd_engine* e, int prog, int idx, int want_grad, float* host_out, int* info4);
+int dd_debug_num_tensors(struct dd_engine* e, int prog);
+/* parity-test hook: evaluate the guide network of every later guided forward AT these images (DEVICE fp32 [count][B,3,8L,8L], the
+ * decoder's output range, caller-owned; chained guided step k reads image min(k, count-1)) instead of the decoder's own output;
+ * gradients still flow through the decoder.  The input-gradient of the ReLU / max-pool guide is piecewise constant in the image, so
+ * two implementations of torch.autograd.grad(E, ...) (generate_data.py:721, :761) can only be compared at the same image.
+ * NULL / count 0 switches it off.  dd_debug_set_image = count 1. */
+int dd_debug_set_images(struct dd_engine* e, const float* images, int count);
+int dd_debug_set_image(struct dd_engine* e, const float* image);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,183 @@
+"""Parity AT THE BENCHMARKED BATCH (BASELINE.json configs[1] shapes, engine batch 16 and 32 = what bench.py runs): every row of an
+engine batch against the fp32 CPU oracle's full-size fixtures, through the production C ABI.
+
+At B = 1 (tests/test_fullsize_gpu.py) the UNet's GEMMs have M = 4096-8192 rows and mostly run split-K; at B = 32 M is 262144 - 8.4 M,
+nothing splits, the two-workgroup conv forms run 1000-tile grids and the VAE's 512x512 levels cross the 32-bit byte-offset limit of the
+fast staging path.  Those are different kernels and different launch geometries: this file is the parity evidence for them.
+
+Rows alternate between two independent inputs (latents, e, b, prompt, class): row "a" = the inputs of fullsize_fixture.pt, row "b" =
+make_fullsize_p2_fixture.inputs2; references: tests/golden/fullsize_p2_fixture.pt (both rows: plain step, P = 1 and the script of
+record's chained P = 2 transform guidance, generate_data.py:687-732, expand_diff.sh:6) and fullsize_fixture.pt (row a: direct guidance
+with the StanfordCars sizes, generate_data.py:735-767).  Tolerances are those of tests/test_fullsize_gpu.py (relative L2 vs fp32):
+eps / z_next / x0 / image <= 3 %; scores 1e-4 at the oracle's image; energy gradients at the oracle's image: per-pixel <= 6 % (P = 1)
+and <= 8 % (two chained steps), (ge, gb) <= 5 % / 8 %; updated latents <= 5 % / 7 %; own forward point: score 0.5 %, latents 6 % / 8 %.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    assert torch.isfinite(a).all()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _batches():
+    b = os.environ.get("DD_TEST_BATCHES")
+    return [int(x) for x in b.split(",")] if b else [16, 32]
+
+
+@pytest.fixture(scope="module", params=_batches())
+def world(request, hip_lib):
+    from make_fullsize_fixture import inputs
+    from make_fullsize_p2_fixture import inputs2
+    from distdiff_amd.config import sd15_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    B = request.param
+    free, _ = torch.cuda.mem_get_info()
+    need = (7.6e9 * B + 8e9)          # two chained activation stashes: ~7.5 GB per image
+    if free < need:
+        pytest.skip("engine batch %d needs ~%.0f GB of HBM, %.0f GB free" % (B, need / 1e9, free / 1e9))
+    fx1 = torch.load(os.path.join(HERE, "golden", "fullsize_fixture.pt"), weights_only=False)
+    fx2 = torch.load(os.path.join(HERE, "golden", "fullsize_p2_fixture.pt"), weights_only=False)
+    cfg = sd15_config(latent_size=64, max_batch=B)
+    w = synthetic_weights(cfg, seed=0, num_classes=100)
+    chk = float(sum(v.double().sum() for v in w["unet"].values()))
+    assert abs(chk - fx2["weights_checksum"]) <= 1e-6 * abs(fx2["weights_checksum"]), "synthetic weights differ from the fixture's"
+    eng = Engine(cfg, w, enable_grad=True, max_guidance_period=2)
+    sched = DDIMSchedule(cfg.scheduler)
+    ts = sched.set_timesteps(50)
+    assert [int(ts[fx2["step_index"]]), int(ts[fx2["step_index"] + 1])] == fx2["t"]
+    da, db = inputs(cfg), inputs2(cfg)
+    rows = ["a" if i % 2 == 0 else "b" for i in range(B)]
+    pick = lambda k: torch.cat([(da if r == "a" else db)[k] for r in rows])      # noqa: E731
+    inp = {k: pick(k) for k in ("z", "e", "b", "neg", "pos", "t100")}
+    inp["t196"] = torch.cat([da["t196"] if r == "a" else torch.tensor([33]) for r in rows])
+    eng.set_prompt(torch.cat([inp["neg"], inp["pos"]]).cuda())
+    eng.set_sample_weights([1.0] * B)          # train_batch_size = 1: every row is its own reference batch (generate_data.py:709)
+
+    def schedule(P):
+        eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=7.5, gs=1.0, ls=1.0, rho=10.0,
+                         constraint_value=0.2, guidance_period=P)
+
+    def ref(key):       # the fixture's per-row reference, stacked in engine-batch order
+        return torch.cat([fx2[r][key].float() for r in rows])
+
+    yield {"B": B, "cfg": cfg, "eng": eng, "rows": rows, "inp": inp, "fx1": fx1, "fx2": fx2, "ref": ref, "schedule": schedule,
+           "da": da, "db": db}
+    eng.close()
+
+
+def _per_row(got, want, tol, what, rows):
+    errs = [rel(got[i:i + 1], want[i:i + 1]) for i in range(len(rows))]
+    bad = [(i, rows[i], round(e, 4)) for i, e in enumerate(errs) if not e < tol]
+    assert not bad, "%s: rows over %.3g: %s" % (what, tol, bad)
+    return max(errs)
+
+
+def test_plain_step_and_decode_every_row(world):
+    """denoise_one_step (generate_data.py:109-121) + vae.decode (:1223) on B different rows."""
+    w = world
+    eng, B, rows, inp, ref, fx2 = w["eng"], w["B"], w["rows"], w["inp"], w["ref"], w["fx2"]
+    w["schedule"](2)
+    si = fx2["step_index"]
+    z0 = inp["z"] * (1 + inp["e"]) + inp["b"]
+    eps2 = eng.unet_forward(z0, si)                           # [2B]: unconditional half first
+    e_ref = torch.cat([torch.cat([fx2[r]["eps2"][h:h + 1] for r in rows]) for h in (0, 1)])
+    m0 = _per_row(eps2, e_ref, 0.03, "eps2", rows + rows)
+    zp, x0 = eng.denoise_step(z0, si)
+    m1 = _per_row(zp, ref("z1"), 0.03, "z_next", rows)
+    m2 = _per_row(x0, ref("x0_1"), 0.03, "x0", rows)
+    # second chained timestep from the oracle's z1
+    zp2, x02 = eng.denoise_step(ref("z1"), si + 1)
+    m3 = _per_row(zp2, ref("z2"), 0.03, "z_next(t1)", rows)
+    m4 = _per_row(x02, ref("x0_2"), 0.03, "x0(t1)", rows)
+    # the decoder: at 512x512 and B = 32 its 128/256-channel levels are 4.3 / 8.6 GB tensors (general staging path of conv_gemm2.hip)
+    img = eng.decode(ref("x0_1"), denormalize=False)
+    m5 = _per_row(img, ref("image_1"), 0.03, "decoded image", rows)
+    print("B=%d max row errors: eps2 %.4f z_next %.4f x0 %.4f | t1: %.4f %.4f | image %.4f" % (B, m0, m1, m2, m3, m4, m5))
+
+
+def _transform(w, P):
+    eng, rows, inp, ref, fx2 = w["eng"], w["rows"], w["inp"], w["ref"], w["fx2"]
+    w["schedule"](P)
+    eng.set_prototypes(w["da"]["Pc100"], w["da"]["Pg100"])
+    si = fx2["step_index"]
+    pre = "p%d_" % P
+    s_ref = ref(pre + "score").reshape(-1)
+    # own forward point: scores and the updated latents
+    eng.set_guide_image(None)
+    z_own, score, _ = eng.transform_guidance(inp["z"], inp["t100"], inp["e"], inp["b"], si, P)
+    sc = eng.image_scores().cpu()
+    assert ((sc - s_ref).abs() <= 0.005 * s_ref.abs()).all(), (sc, s_ref)
+    assert abs(score.item() - float(s_ref.sum())) <= 0.005 * float(s_ref.sum())       # sum_i w_i E_i with w_i = 1
+    assert float((z_own.cpu() - inp["z"]).abs().max()) <= 0.2 + 1e-5               # linfball_proj (:124-137)
+    # the guide's masks at the oracle's images: the hand-derived VJP itself
+    imgs = torch.stack([ref("image_%d" % (k + 1)) for k in range(P)])               # [P, B, 3, 512, 512]
+    eng.set_guide_image(imgs)
+    z_same, _, gz = eng.transform_guidance(inp["z"], inp["t100"], inp["e"], inp["b"], si, P)
+    sc2 = eng.image_scores().cpu()
+    eng.set_guide_image(None)
+    assert ((sc2 - s_ref).abs() <= 1e-4 * s_ref.abs()).all(), (sc2, s_ref)
+    gz = gz.cpu()
+    ge = (gz * inp["z"]).sum((2, 3), keepdim=True)
+    gb = gz.sum((2, 3), keepdim=True)
+    return z_own, z_same, gz, ge, gb
+
+
+def test_transform_guidance_one_step_every_row(world):
+    """guidance_period = 1 (the configuration of test_fullsize_gpu.py), B rows with their own latents / e / b / prompt / class."""
+    w = world
+    rows, ref = w["rows"], w["ref"]
+    z_own, z_same, gz, ge, gb = _transform(w, 1)
+    m = (_per_row(gz, ref("p1_gz0"), 0.06, "dE/dz0", rows), _per_row(ge, ref("p1_ge"), 0.05, "ge", rows),
+         _per_row(gb, ref("p1_gb"), 0.05, "gb", rows), _per_row(z_same, ref("p1_z"), 0.05, "z_new (same image)", rows),
+         _per_row(z_own, ref("p1_z"), 0.06, "z_new (own forward)", rows))
+    print("B=%d P=1 max row errors: gz0 %.4f ge %.4f gb %.4f z_new %.4f (same image) %.4f (own forward)" % ((w["B"],) + m))
+
+
+def test_transform_guidance_two_chained_steps_every_row(world):
+    """The script of record: guidance_period = 2 (expand_diff.sh:6), two chained guided steps at t = 381, 361 with the carry
+    sqrt(a') g_z' through the DDIM step (generate_data.py:699-719)."""
+    w = world
+    rows, ref = w["rows"], w["ref"]
+    z_own, z_same, gz, ge, gb = _transform(w, 2)
+    m = (_per_row(gz, ref("p2_gz0"), 0.08, "dE/dz0", rows), _per_row(ge, ref("p2_ge"), 0.08, "ge", rows),
+         _per_row(gb, ref("p2_gb"), 0.08, "gb", rows), _per_row(z_same, ref("p2_z"), 0.07, "z_new (same image)", rows),
+         _per_row(z_own, ref("p2_z"), 0.08, "z_new (own forward)", rows))
+    print("B=%d P=2 max row errors: gz0 %.4f ge %.4f gb %.4f z_new %.4f (same image) %.4f (own forward)" % ((w["B"],) + m))
+
+
+def test_direct_guidance_every_row(world):
+    """configs[3]'s guided step (generate_data.py:735-767, C = 196): "a" rows against fullsize_fixture.pt, "b" rows (no oracle run of
+    their own) must agree with each other -- they are the same computation at different batch positions."""
+    w = world
+    eng, rows, inp, fx1, B = w["eng"], w["rows"], w["inp"], w["fx1"], w["B"]
+    w["schedule"](2)
+    eng.set_prototypes(w["da"]["Pc196"], w["da"]["Pg196"])
+    si = fx1["step_index"]
+    z0 = inp["z"] * (1 + inp["e"]) + inp["b"]
+    ia = [i for i, r in enumerate(rows) if r == "a"]
+    ib = [i for i, r in enumerate(rows) if r == "b"]
+    imgs = torch.cat([fx1["image"] if r == "a" else w["fx2"]["b"]["image_1"].float() for r in rows])
+    eng.set_guide_image(imgs)
+    zn, x0, score, gz = eng.direct_guidance(z0, inp["t196"], si)
+    sc = eng.image_scores().cpu()
+    eng.set_guide_image(None)
+    s_ref = float(fx1["direct_score"])
+    for i in ia:
+        assert abs(float(sc[i]) - s_ref) <= 1e-4 * abs(s_ref)
+        assert rel(gz[i:i + 1], fx1["direct_gz"]) < 0.06, (i, rel(gz[i:i + 1], fx1["direct_gz"]))
+        assert rel(zn[i:i + 1], fx1["direct_z_next"]) < 0.03 and rel(x0[i:i + 1], fx1["x0"]) < 0.03
+    for i in ib[1:]:
+        assert rel(gz[i:i + 1], gz[ib[0]:ib[0] + 1]) < 1e-2 and rel(zn[i:i + 1], zn[ib[0]:ib[0] + 1]) < 1e-3
+    print("B=%d direct: row-a g_z rel %.4f" % (B, rel(gz[ia[0]:ia[0] + 1], fx1["direct_gz"])))

@@ -109,6 +109,35 @@ def test_conv_forward_and_dgrad(ops, case):
         assert_close(ops.from_nhwc(dxs, B, H, W), g2, rtol=2.5e-2, what=name + " dgrad+sumpool")
 
 
+def test_conv_general_staging_path_beyond_4gb(ops):
+    """The decoder's 256-channel 512x512 level at the benchmarked batch: 34 x 512 x 512 x 256 bf16 = 4.56 GB of input.  The fast staging
+    path of conv_gemm2.hip addresses the input through 32-bit BYTE offsets of a buffer resource, so inputs of 3.75 GB and more take the
+    general path (32-bit element offsets, global_load_lds): images before, across and beyond the 2^32-byte boundary are checked
+    against F.conv2d on the CPU, forward (256 -> 128, 3x3) and through the residual / bias epilogue."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12e9:
+        pytest.skip("needs 12 GB of free HBM")
+    B, Cin, Cout, H, W = 34, 256, 128, 512, 512
+    g = torch.Generator().manual_seed(99)
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    bias = torch.randn(Cout, generator=g)
+    pk = ops.PackedConv(w, 1, mode=0, bias=bias)
+    gg = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((B * H * W, Cin), device="cuda", dtype=torch.bfloat16)
+    for b in range(B):       # image by image: torch.randn of 2.2e9 elements at once would need a 9 GB fp32 temporary
+        x[b * H * W:(b + 1) * H * W] = torch.randn((H * W, Cin), device="cuda", generator=gg).to(torch.bfloat16)
+    assert x.numel() * 2 >= 0xF0000000
+    res = torch.empty((B * H * W, Cout), device="cuda", dtype=torch.bfloat16)
+    res.copy_(x[:, :Cout])
+    y = ops.conv_gemm(x, pk, B, H, W, H, W, res=res, ksplit=1)
+    torch.cuda.synchronize()
+    for b in (0, 31, 32, 33):     # image 32 starts exactly at byte 2^32 of the input
+        xi = x[b * H * W:(b + 1) * H * W].float().cpu().reshape(1, H, W, Cin).permute(0, 3, 1, 2)
+        ref = F.conv2d(xi, w, bias, padding=1) + xi[:, :Cout]
+        got = y[b * H * W:(b + 1) * H * W].float().cpu().reshape(1, H, W, Cout).permute(0, 3, 1, 2)
+        assert_close(got, ref, what="general path, image %d" % b)
+
+
 def test_linear_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, K, N = 300, 320, 640
@@ -135,6 +164,21 @@ def test_linear_epilogues(ops):
     ops.conv_gemm(xd, pk, 1, M, 1, M, 1, y=big[:, 64:], ksplit=1)
     assert_close(big[:, 64:], ref, what="linear strided out")
     assert float(big[:, :64].float().abs().max()) == 0.0
+
+
+def test_pointwise_launch_requires_the_centre_tap(ops):
+    """dd_op_conv_gemm: a one-tap, stride-1, same-size launch is a 1x1 / linear layer; the persistent kernel does not read its tap
+    table, so the ABI rejects a table that holds anything but the centre tap instead of silently computing the centre tap."""
+    from distdiff_amd import _lib
+    g = torch.Generator().manual_seed(12)
+    M, K, N = 2048, 256, 256
+    x = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+    pk = ops.PackedConv(bf(torch.randn(N, K, generator=g) / 16), 0)
+    assert int(pk.taptab[0]) == (32 << 6) | 32
+    ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
+    pk.taptab[0] = ((32 + 1) << 6) | 32          # dy = +1
+    with pytest.raises(RuntimeError):
+        ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
 
 
 @pytest.mark.parametrize("M,K,Fd", [(200, 128, 256), (1500, 320, 1280)])
@@ -237,6 +281,47 @@ def test_attention(ops, case):
     if not cross:
         assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what=name + " dK")
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
+
+
+@pytest.mark.parametrize("D,H", [(40, 8), (80, 8)])
+def test_attention_4096_keys_peaky_logits(ops, D, H):
+    """The UNet's 64x64 self-attention (4096 queries x 4096 keys, d = 40; d = 80 at 32x32 uses the same kernel) with PEAKY logits:
+    scaled scores of standard deviation >= 4 and row maxima that keep rising along the key axis, so the online softmax rescales in
+    most of its 64 key tiles (synthetic fan_in^-1/2 weights give near-uniform scores, which never exercise that path at full length)."""
+    B, Nq, Nk = 1, 4096, 4096
+    g = torch.Generator().manual_seed(41)
+    scale = 1.0 / math.sqrt(D)
+    amp = 2.0                                               # q.k / sqrt(D) of N(0, amp^2) entries has sigma amp^2 = 4
+    q = bf(torch.randn(B, Nq, H, D, generator=g) * amp)
+    k = bf(torch.randn(B, Nk, H, D, generator=g) * amp)
+    # a drift along the key axis (up to +12 in the scaled score): later keys align more with a direction every query shares, so the
+    # running maxima keep moving tile after tile
+    u = torch.randn(H, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    a = math.sqrt(12.0 * math.sqrt(D))
+    q = bf(q + a * u)
+    k = bf(k + (torch.linspace(0, 1, Nk)[None, :, None, None] * a) * u)
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    assert float(s.std()) >= 4.0, float(s.std())
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    o, lse = ops.attention(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale)
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref, rtol=2e-2, atol=2e-3, what="peaky O")
+    assert_close(lse, torch.logsumexp(s, dim=-1), rtol=1e-3, atol=2e-3, what="peaky LSE")
+    # backward on the same scores: dQ, dK, dV against autograd on a 512-query slice (the full 4096^2 x 8 autograd graph is 2 GB)
+    Ns = 512
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q[:, :Ns], k, v))
+    ss = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    rs = torch.einsum("bhqk,bkhd->bqhd", ss.softmax(-1), vr)
+    d_o = bf(torch.randn(B, Ns, H, D, generator=g))
+    gq, gk, gv = torch.autograd.grad(rs, (qr, kr, vr), d_o)
+    o2, lse2, dq, dk, dv = ops.attention(dev(q[:, :Ns], Ns), dev(k, Nk), dev(v, Nk), B, H, Ns, Nk, D, scale, d_o=dev(d_o, Ns))
+    torch.cuda.synchronize()
+    assert_close(dq.reshape(B, Ns, H, D), gq, rtol=3e-2, atol=3e-3, what="peaky dQ")
+    assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what="peaky dK")
+    assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what="peaky dV")
 
 
 @pytest.mark.parametrize("case", [("vae_mid_d512", 2, 1, 1024, 1024, 512), ("wide_2heads_d256", 1, 2, 512, 768, 256)], ids=lambda c: c[0])
