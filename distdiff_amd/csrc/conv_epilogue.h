@@ -12,6 +12,15 @@ struct Epi {
     const int flags = p.flags;
     int ncols;  // logical output columns
     int ob;     // output column base
+    if (flags & CF_LNFOLD) {
+      // LayerNorm folded into this GEMM (kernels.h CF_LNFOLD): acc -> rstd * (acc - mean * c1[n]); the folded bias follows as usual
+      const float mean = p.ln_stats[(size_t)m * 2], rstd = p.ln_stats[(size_t)m * 2 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r < p.N) h[r] = rstd * (h[r] - mean * p.ln_c1[nb + r]);
+        if ((flags & CF_GEGLU) && nb_gate + r < p.N) g[r] = rstd * (g[r] - mean * p.ln_c1[nb_gate + r]);
+      }
+    }
     if (flags & CF_GEGLU) {
       ncols = p.N >> 1;
       ob = (nb >> 5) * 16 + (nb & 15);

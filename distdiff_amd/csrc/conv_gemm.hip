@@ -336,8 +336,30 @@ bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes) {
   return true;
 }
 
+int conv_gemm_big_rowstat_span(int cfg);
+
+bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int* spans) {
+  if ((p.K & 63) || p.M <= 0 || p.N <= 0 || (p.N & 7) || (p.y_ld & 7)) return false;
+  if (p.flags & (CF_GEGLU | CF_OUT_F32 | CF_MASK | CF_RES_F32 | CF_STATS | CF_LNFOLD)) return false;
+  if ((p.flags & CF_RES) && (p.res_ld & 7)) return false;
+  // the batched epilogue of the two-workgroup pointwise forms only (fast staging: Cin % 64 == 0, one tap, no upsample)
+  if ((p.cin & 63) || p.shift || p.ntaps != 1 || p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
+  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return false;
+  int cfg, split;
+  select_config(p, partial_cap_bytes, &cfg, &split);
+  const int span = cfg ? conv_gemm_big_rowstat_span(cfg) : 0;
+  if (!span || split != 1 || p.N % (2 * span)) return false;
+  if (spans) *spans = p.N / span;
+  return true;
+}
+
 hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
   if (p.K & 63) return hipErrorInvalidValue;
+  if ((p.flags & CF_LNFOLD) && (!p.ln_stats || !p.ln_c1 || p.ntaps != 1)) return hipErrorInvalidValue;
+  if (p.flags & CF_ROWSTATS) {
+    int spans = 0;
+    if (!p.rowpart || !conv_gemm_can_emit_rowstats(p, partial_cap_bytes, &spans) || p.rowpart_ld < spans) return hipErrorInvalidValue;
+  }
   // the kernels index the input with 32-bit element offsets (outputs and residuals use 64-bit offsets)
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0xFFFF0000ull) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;

@@ -59,9 +59,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // FM: 1 = fast staging path only (Cin % 64 == 0, no fused upsample / dilation, <= 32 taps: buffer loads with scalar tap offsets),
 //     0 = general path only (per-lane address arithmetic, global_load_lds).  FE: batched epilogue compiled in.
-// ST: the CF_STATS epilogue is compiled in (its own instantiation: the code of the plain kernels -- above all the register allocation
-// of their K loop -- stays exactly what it was without it).
-template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
+// ST: epilogue extras, each its own instantiation (the code of the plain kernels -- above all the register allocation of their K
+// loop -- stays exactly what it was without them): 1 = CF_STATS (GroupNorm partials), 2 = CF_ROWSTATS (LayerNorm row partials),
+// 3 = CF_LNFOLD (this GEMM consumes the raw input of a LayerNorm folded into its weights; c1 arrives through a second LDS ring).
+template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, int ST>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm_big_kernel(ConvGemmParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int NW = WM * WN;   // 8 waves (one workgroup per CU) or 4 waves (two workgroups per CU, <= 256 VGPRs each)
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   // at most two items ahead of the epilogue), read from LDS by the batched epilogue -- a global load there costs an exposed L2 / HBM
   // latency per item (tools/conv_trace.py: 3 us of epilogue on a 5-step item, half of it the bias wait)
   constexpr int BIAS_OFF = NS * BUF_BYTES + 256;
+  constexpr int C1_OFF = BIAS_OFF + 3 * 1024;     // ST == 3: column sums of the LayerNorm-folded weights, same ring discipline
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -183,6 +185,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       const int nb = n0 + lane * 4;
       const unsigned voff = ((p.flags & CF_BIAS) && lane * 4 < BN && nb + 4 <= p.N) ? (unsigned)nb * 4u : OOB;
       dma16(bias, smem + BIAS_OFF + l_slot * 1024, voff, 0);
+      if constexpr (ST == 3) {
+        const unsigned v1 = (lane * 4 < BN && nb + 4 <= p.N) ? (unsigned)nb * 4u : OOB;
+        dma16(p.ln_c1, smem + C1_OFF + l_slot * 1024, v1, 0);
+      }
       l_slot = l_slot == 2 ? 0 : l_slot + 1;
     }
 #pragma unroll
@@ -376,7 +382,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     const int ncol0 = n0 + wn * (TN * 16) + fq * 4;
     const bool tile_full = (n0 + wn * (TN * 16) + TN * 16 <= p.N) && !(p.y_ld & 7) && !(p.N & 7);
     const int fl = p.flags;
-    if (tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
+    // (a CF_LNFOLD launch that did not get its ST == 3 instantiation -- an eight-wave or general-staging form -- takes the generic
+    //  epilogue below, whose Epi::apply folds from global memory)
+    const bool fold_ok = ST == 3 || !(fl & CF_LNFOLD);
+    if (fold_ok && tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
       // 16-byte loads / stores per tile pair; bias and every residual row are requested before the first use.  (Keeping the
       // bias in registers from the start of the item was measured slower: 20 VGPRs live across the K loop, tools/ab_ops.sh.)
       const int wb = n0 + wn * (TN * 16);
@@ -397,49 +406,94 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
         }
       }
       float s1[TN][4], s2[TN][4];
-      if (ST && (fl & CF_STATS)) {
+      if (ST == 1 && (fl & CF_STATS)) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
       }
+      // ST == 3: LayerNorm folded into this GEMM: out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n]; ST == 2: per-row (sum, sum^2)
+      float4 cv[ST == 3 ? TN : 1];
+      float2 lnst[ST == 3 ? TM : 1];
+      float rs1[ST == 2 ? TM : 1], rs2[ST == 2 ? TM : 1];
+      if constexpr (ST == 3) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) cv[jn] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (wn * (TN * 16) + col_of(jn)) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lnst[i] = *(const float2*)(p.ln_stats + (size_t)min(m0 + wm * (TM * 16) + i * 16 + fr, p.M - 1) * 2);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+        if constexpr (ST == 2) { rs1[i] = 0.f; rs2[i] = 0.f; }
         if (m >= p.M) continue;
         bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
-        auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1, float* t1, float* t2) {
-          float v0 = a[0] * p.alpha + b.x, v1 = a[1] * p.alpha + b.y, v2 = a[2] * p.alpha + b.z, v3 = a[3] * p.alpha + b.w;
+        auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1, float* t1, float* t2, int jn) {
+          float v0, v1, v2, v3;
+          if constexpr (ST == 3) {
+            const float mu = lnst[i].x, rs = lnst[i].y;
+            v0 = __builtin_fmaf(rs, a[0] * p.alpha - mu * cv[jn].x, b.x); v1 = __builtin_fmaf(rs, a[1] * p.alpha - mu * cv[jn].y, b.y);
+            v2 = __builtin_fmaf(rs, a[2] * p.alpha - mu * cv[jn].z, b.z); v3 = __builtin_fmaf(rs, a[3] * p.alpha - mu * cv[jn].w, b.w);
+          } else {
+            v0 = a[0] * p.alpha + b.x; v1 = a[1] * p.alpha + b.y; v2 = a[2] * p.alpha + b.z; v3 = a[3] * p.alpha + b.w;
+          }
           if (fl & CF_RES) {
             v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
             v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
           }
           if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-          if (ST && (fl & CF_STATS)) {
+          if (ST == 1 && (fl & CF_STATS)) {
             t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
             t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
             t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
+          }
+          if constexpr (ST == 2) {
+            rs1[i] += (v0 + v1) + (v2 + v3);
+            rs2[i] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, rs2[i]))));
           }
           return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
         };
 #pragma unroll
         for (int t = 0; t < TN / 2; ++t) {
-          const uint2 lo = four(acc[2 * t][i], bv[2 * t], rvp[i][t].x, rvp[i][t].y, s1[2 * t], s2[2 * t]);
-          const uint2 hi = four(acc[2 * t + 1][i], bv[2 * t + 1], rvp[i][t].z, rvp[i][t].w, s1[2 * t + 1], s2[2 * t + 1]);
+          const uint2 lo = four(acc[2 * t][i], bv[2 * t], rvp[i][t].x, rvp[i][t].y, s1[2 * t], s2[2 * t], 2 * t);
+          const uint2 hi = four(acc[2 * t + 1][i], bv[2 * t + 1], rvp[i][t].z, rvp[i][t].w, s1[2 * t + 1], s2[2 * t + 1], 2 * t + 1);
           *(uint4*)(yp + cp + 32 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y, s1[TN - 1], s2[TN - 1]);
+        if constexpr (TN & 1) *(uint2*)(yp + co) = four(acc[TN - 1][i], bv[TN - 1], rvo[i].x, rvo[i].y, s1[TN - 1], s2[TN - 1], TN - 1);
       }
-      if (ST && (fl & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), wb);
+      if (ST == 1 && (fl & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), wb);
+      if constexpr (ST == 2) {
+        // a row's TN * 16 columns of this wave sit in the 4 lanes fr, fr + 16, fr + 32, fr + 48: two xor-shuffles, lanes 0-15 store
+        // (sum, sum^2) of their rows into span (n-tile * WN + wn) of the row
+        const int span = (n0 / BN) * WN + wn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float a = rs1[i], q = rs2[i];
+          a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+          a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+          const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+          if (fq == 0 && m < p.M) *(float2*)(p.rowpart + ((size_t)m * p.rowpart_ld + span) * 2) = make_float2(a, q);
+        }
+      }
       return;
     }
     if constexpr ((TN & 1) == 0) {
-      if (tile_full && (fl & CF_GEGLU) && !(fl & (CF_MASK | CF_RES | CF_OUT_F32)) && !(p.raw_ld & 3)) {
+      if (fold_ok && tile_full && (fl & CF_GEGLU) && !(fl & (CF_MASK | CF_RES | CF_OUT_F32)) && !(p.raw_ld & 3)) {
         float4 bh[TN / 2], bg[TN / 2];
+        float4 ch[ST == 3 ? TN / 2 : 1], cg[ST == 3 ? TN / 2 : 1];
+        float2 lnst[ST == 3 ? TM : 1];
 #pragma unroll
         for (int t = 0; t < TN / 2; ++t) {
           bh[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
           bg[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
+          if constexpr (ST == 3) {
+            ch[t] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
+            cg[t] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
+          }
+        }
+        if constexpr (ST == 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) lnst[i] = *(const float2*)(p.ln_stats + (size_t)min(m0 + wm * (TM * 16) + i * 16 + fr, p.M - 1) * 2);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -448,10 +502,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #pragma unroll
           for (int t = 0; t < TN / 2; ++t) {
             const int nb = ncol0 + 2 * t * 16;
-            const float h0 = acc[2 * t][i][0] * p.alpha + bh[t].x, h1 = acc[2 * t][i][1] * p.alpha + bh[t].y;
-            const float h2 = acc[2 * t][i][2] * p.alpha + bh[t].z, h3 = acc[2 * t][i][3] * p.alpha + bh[t].w;
-            const float g0 = acc[2 * t + 1][i][0] * p.alpha + bg[t].x, g1 = acc[2 * t + 1][i][1] * p.alpha + bg[t].y;
-            const float g2 = acc[2 * t + 1][i][2] * p.alpha + bg[t].z, g3 = acc[2 * t + 1][i][3] * p.alpha + bg[t].w;
+            float h0, h1, h2, h3, g0, g1, g2, g3;
+            if constexpr (ST == 3) {
+              const float mu = lnst[i].x, rs = lnst[i].y;
+              h0 = __builtin_fmaf(rs, acc[2 * t][i][0] * p.alpha - mu * ch[t].x, bh[t].x); h1 = __builtin_fmaf(rs, acc[2 * t][i][1] * p.alpha - mu * ch[t].y, bh[t].y);
+              h2 = __builtin_fmaf(rs, acc[2 * t][i][2] * p.alpha - mu * ch[t].z, bh[t].z); h3 = __builtin_fmaf(rs, acc[2 * t][i][3] * p.alpha - mu * ch[t].w, bh[t].w);
+              g0 = __builtin_fmaf(rs, acc[2 * t + 1][i][0] * p.alpha - mu * cg[t].x, bg[t].x); g1 = __builtin_fmaf(rs, acc[2 * t + 1][i][1] * p.alpha - mu * cg[t].y, bg[t].y);
+              g2 = __builtin_fmaf(rs, acc[2 * t + 1][i][2] * p.alpha - mu * cg[t].z, bg[t].z); g3 = __builtin_fmaf(rs, acc[2 * t + 1][i][3] * p.alpha - mu * cg[t].w, bg[t].w);
+            } else {
+              h0 = acc[2 * t][i][0] * p.alpha + bh[t].x; h1 = acc[2 * t][i][1] * p.alpha + bh[t].y;
+              h2 = acc[2 * t][i][2] * p.alpha + bh[t].z; h3 = acc[2 * t][i][3] * p.alpha + bh[t].w;
+              g0 = acc[2 * t + 1][i][0] * p.alpha + bg[t].x; g1 = acc[2 * t + 1][i][1] * p.alpha + bg[t].y;
+              g2 = acc[2 * t + 1][i][2] * p.alpha + bg[t].z; g3 = acc[2 * t + 1][i][3] * p.alpha + bg[t].w;
+            }
             if (fl & CF_GEGLU_RAW) {
               bf16_t* rp = p.raw + (size_t)m * p.raw_ld + nb;
               uint2 a, b;
@@ -468,7 +531,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     }
     }  // FE
     float s1[TN][4], s2[TN][4];
-    if (ST && (p.flags & CF_STATS)) {
+    if (ST == 1 && (p.flags & CF_STATS)) {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -499,14 +562,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = acc[jn][i][r];
           Epi::apply(p, bias, m, nb, h, h, 0);     // leaves the stored values (before the bf16 rounding) in h
-          if (ST && (p.flags & CF_STATS)) {
+          if (ST == 1 && (p.flags & CF_STATS)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s1[jn][r] += h[r]; s2[jn][r] = __builtin_fmaf(h[r], h[r], s2[jn][r]); }
           }
         }
       }
     }
-    if (ST && (p.flags & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), n0 + wn * (TN * 16));
+    if (ST == 1 && (p.flags & CF_STATS)) emit_stats(s1, s2, m0 + wm * (TM * 16), n0 + wn * (TN * 16));
   };
 
   // ---- pipeline: NS = 3 LDS stages, software-pipelined through registers.  K-step s reads its two 32-wide halves as
@@ -596,10 +659,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #endif
 }
 
-template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, bool ST>
+template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, int ST>
 hipError_t run_big_fe3(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = NS * (BM + BN) * 128 + 256 + 3 * 1024;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets)
+  constexpr int lds = NS * (BM + BN) * 128 + 256 + (ST == 3 ? 6 : 3) * 1024;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets), bias (+ c1) ring
   static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -611,7 +674,12 @@ hipError_t run_big_fe3(const ConvGemmParams& p, hipStream_t stream) {
 }
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
 hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
-  return (p.flags & CF_STATS) ? run_big_fe3<WM, WN, TM, TN, NS, FE, FM, true>(p, stream) : run_big_fe3<WM, WN, TM, TN, NS, FE, FM, false>(p, stream);
+  // the LayerNorm forms only exist for the batched epilogue of the two-workgroup (shallow-K, pointwise) tiles: conv_gemm_ln_form()
+  if constexpr (WM * WN == 4 && FE && FM == 1) {
+    if (p.flags & CF_LNFOLD) return run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 3>(p, stream);
+    if (p.flags & CF_ROWSTATS) return run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 2>(p, stream);
+  }
+  return (p.flags & CF_STATS) ? run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 1>(p, stream) : run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 0>(p, stream);
 }
 
 template <int WM, int WN, int TM, int TN, int NS, bool FE>
@@ -667,6 +735,9 @@ int conv_gemm_big_config(int M, int N, int K, int flags) {
   if (!geglu && N % 160 == 0) return 2;
   return 0;
 }
+
+// columns per wave of a tile (the span of one CF_ROWSTATS partial): 0 unless the configuration has a row-statistics form
+int conv_gemm_big_rowstat_span(int cfg) { return cfg == 4 ? 80 : cfg == 5 ? 64 : 0; }
 
 void conv_gemm_big_tile(int cfg, int* bm, int* bn) {
   *bm = (cfg == 1 || cfg == 4 || cfg == 5) ? 128 : 256;

@@ -63,6 +63,7 @@ struct ConvW {
   PackedConv sf{}, sb{};
   bf16_t* w_fwd = nullptr; int* tap_fwd = nullptr;
   bf16_t* w_bwd = nullptr; int* tap_bwd = nullptr;
+  float* ln_c1 = nullptr;      // LayerNorm folded into this linear (CF_LNFOLD): column sums of the folded, bf16-rounded weights (packed order)
   float* bias = nullptr;       // [Cout] (packed order for GEGLU) or null
   float* bias_table = nullptr; // [n_steps][Cout] per-timestep effective bias (resnet conv1 + time_emb_proj)
   float* bias_table_img = nullptr;   // SDXL text_time conditioning: [n_steps][2B][Cout], filled by dd_set_added_cond
@@ -108,6 +109,11 @@ struct Op {
   // the fp32 block at part_off (CF_STATS), the GroupNorm op merges them instead of reading the tensor once more
   bool part = false; size_t part_off = 0; int part_ld = 0;
   std::vector<int> producers;
+  // LayerNorm folded into the linear that follows (plan_ln_fold): the OP_LN only produces (mean, rstd) -- from the row partials of
+  // the producing GEMM (rowstat_from = its op index, CF_ROWSTATS) when that GEMM can emit them, else from one read of the tensor --
+  // and the OP_CONV reads the LayerNorm's INPUT (x_fwd) with CF_LNFOLD; the backward plan is untouched (x stays the LayerNorm output)
+  bool ln_fold = false; int x_fwd = -1; size_t ln_stats_off = 0;
+  int rowstat_from = -1; bool rowstat_emit = false; int rowstat_ld = 0;
   double flops = 0;
 };
 
@@ -119,6 +125,8 @@ struct Program {
   bool want_grad = false;
   bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
   mutable std::vector<char> emitted;   // per op, per forward run: this convolution did emit its GroupNorm partials
+  mutable std::vector<int> row_spans;  // per op, per forward run: column spans of the LayerNorm row partials this GEMM emitted (0 = none)
+  size_t scratch_rowpart = 0;          // bytes of the shared row-partial buffer (producer GEMM -> LayerNorm statistics, adjacent ops)
   size_t tr_max = 0;     // bytes of one transient ping-pong buffer
   int tr_count = 0;
   int transient(int B, int H, int W, int C, bool grad = true) {
@@ -191,6 +199,7 @@ struct Ctx {  // per-call execution context
   char* scratch_partial = nullptr; size_t partial_cap = 0;
   char* scratch_tmp = nullptr;
   float* gn_scratch = nullptr;
+  float* rowpart = nullptr;      // LayerNorm row partials of the GEMM that ran last (CF_ROWSTATS)
   const int* tap1x1 = nullptr;   // device int: the 1x1 tap, for GEMMs issued outside a ConvW (wide-head attention)
   size_t tmp_cap = 0;
   int step_index = 0;
@@ -260,6 +269,7 @@ struct dd_engine {
   char* scratch_partial = nullptr; size_t partial_cap = 0;
   char* scratch_tmp = nullptr; size_t tmp_cap = 0;
   float* gn_scratch = nullptr;
+  float* rowpart = nullptr;
   int* tap1x1 = nullptr;
   float* f32_tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B,4,L,L] fp32 temporaries
   float* img_tmp = nullptr;    // [B,3,8L,8L] fp32
@@ -352,11 +362,31 @@ ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, 
   return E->convs.back().get();
 }
 
-// has_bias is passed explicitly: a shape-only engine has no host data to look at
+// has_bias is passed explicitly: a shape-only engine has no host data to look at.
+// ln_gamma / ln_beta (host, [Cin]; `fold` tells a shape-only engine): the LayerNorm in front of this linear is folded into it --
+//   LN(x) W^T + b = rstd * (x (gamma o W)^T - mean * c1) + (b + W beta),  c1[n] = sum_k (gamma o W)[n, k]
+// (kernels.h CF_LNFOLD): the FORWARD packing holds gamma o W, the bias W beta + b, ln_c1 the column sums of the bf16-rounded folded
+// weights (the rank-1 correction must cancel what the MFMAs actually accumulate); the input-gradient packing keeps the plain W, the
+// LayerNorm's own backward multiplies by gamma as before.
 ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_bias, int Cout, int Cin, int KH, int KW, int pad,
-                     bool geglu, bool need_bwd) {
+                     bool geglu, bool need_bwd, bool fold = false, const float* ln_gamma = nullptr, const float* ln_beta = nullptr) {
   auto cw = std::make_unique<ConvW>();
   cw->Cout = Cout; cw->Cin = Cin; cw->KH = KH; cw->KW = KW; cw->pad = pad; cw->geglu = geglu;
+  if (fold && (KH != 1 || KW != 1)) throw std::runtime_error("LayerNorm folding needs a linear layer");
+  std::vector<float> wfold, bfold, c1;
+  if (fold && !E->shape_only) {
+    wfold.resize((size_t)Cout * Cin); bfold.assign(Cout, 0.f); c1.assign(Cout, 0.f);
+    for (int n = 0; n < Cout; ++n) {
+      double sb = bias ? bias[n] : 0.0, sc = 0.0;
+      for (int k = 0; k < Cin; ++k) {
+        const float wf = w[(size_t)n * Cin + k] * ln_gamma[k];
+        wfold[(size_t)n * Cin + k] = wf;
+        sb += (double)w[(size_t)n * Cin + k] * ln_beta[k];
+        sc += host_bf2f(host_f2bf(wf));
+      }
+      bfold[n] = (float)sb; c1[n] = (float)sc;
+    }
+  }
   for (int mode = 0; mode < (need_bwd ? 2 : 1); ++mode) {
     PackedConv& sh = mode ? cw->sb : cw->sf;
     sh = pack_conv_shape(Cout, Cin, KH, KW, mode);
@@ -364,36 +394,45 @@ ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_b
     std::vector<int> tt;
     if (!E->shape_only) {
       wp.resize((size_t)sh.N * sh.K); tt.resize(sh.ntaps);
-      pack_conv_weight(w, Cout, Cin, KH, KW, pad, mode, geglu, wp.data(), tt.data());
+      pack_conv_weight((fold && mode == 0) ? wfold.data() : w, Cout, Cin, KH, KW, pad, mode, geglu, wp.data(), tt.data());
     }
     bf16_t* d = (bf16_t*)E->wupload(wp.data(), (size_t)sh.N * sh.K * 2);
     int* t = (int*)E->wupload(tt.data(), (size_t)sh.ntaps * 4);
     if (mode) { cw->w_bwd = d; cw->tap_bwd = t; } else { cw->w_fwd = d; cw->tap_fwd = t; }
   }
-  if (has_bias) {
-    std::vector<float> b;
+  if (has_bias || fold) {
+    std::vector<float> b, c;
     if (!E->shape_only) {
       b.resize(Cout);
-      for (int n = 0; n < Cout; ++n) b[n] = bias[geglu ? geglu_perm(n, Cout / 2) : n];
+      const float* src = fold ? bfold.data() : bias;
+      for (int n = 0; n < Cout; ++n) b[n] = src[geglu ? geglu_perm(n, Cout / 2) : n];
+      if (fold) { c.resize(Cout); for (int n = 0; n < Cout; ++n) c[n] = c1[geglu ? geglu_perm(n, Cout / 2) : n]; }
     }
     cw->bias = (float*)E->wupload(b.data(), (size_t)Cout * 4);
+    if (fold) cw->ln_c1 = (float*)E->wupload(c.data(), (size_t)Cout * 4);
   }
   E->convs.push_back(std::move(cw));
   return E->convs.back().get();
 }
 
+inline bool ln_fold_enabled() { static const bool on = !getenv("DD_NO_LN_FOLD"); return on; }
+
+// ln: prefix of the LayerNorm to fold into this linear ("" = none)
 ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& prefix, int pad, bool geglu = false,
-                 bool has_bias = true) {
+                 bool has_bias = true, const std::string& ln = "") {
   const HostTensor& w = E->get(model, prefix + ".weight");
   const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
   const int KH = w.shape.size() == 4 ? (int)w.shape[2] : 1, KW = w.shape.size() == 4 ? (int)w.shape[3] : 1;
   const bool hb = has_bias && E->has(model, prefix + ".bias");
   const float* b = hb ? E->get(model, prefix + ".bias").data.data() : nullptr;
-  return make_conv_raw(E, w.data.data(), b, hb, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0);
+  const bool fold = !ln.empty();
+  return make_conv_raw(E, w.data.data(), b, hb, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0, fold,
+                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr);
 }
 
 // several linears sharing the input, concatenated along Cout (fused QKV)
-ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias) {
+ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias,
+                     const std::string& ln = "") {
   std::vector<float> w, b;
   int Cin = 0, Cout = 0;
   for (auto& p : prefixes) {
@@ -403,7 +442,9 @@ ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<s
     w.insert(w.end(), t.data.begin(), t.data.end());
     if (with_bias) { const HostTensor& bb = E->get(model, p + ".bias"); b.insert(b.end(), bb.data.begin(), bb.data.end()); }
   }
-  return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, with_bias, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0);
+  const bool fold = !ln.empty();
+  return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, with_bias, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0, fold,
+                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr);
 }
 
 // conv (no bias) followed by eval-mode BatchNorm, folded: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)
@@ -489,6 +530,28 @@ struct Builder {
     op.stats_off = P.fp32_block((size_t)tx.B * G * 2);
     P.ops.push_back(op);
     return y;
+  }
+  // The LayerNorm and the linear just built (the last two ops) become one: the linear's forward packing already holds gamma o W
+  // (make_conv(..., ln)), it reads the LayerNorm's input with CF_LNFOLD and the LayerNorm op only produces (mean, rstd) -- taken from
+  // the row partials of the GEMM that produced its input when that GEMM is the op right in front of it (CF_ROWSTATS).
+  void fold_ln() {
+    const int ci = (int)P.ops.size() - 1, li = ci - 1;
+    if (li < 0 || P.ops[ci].kind != OP_CONV || P.ops[li].kind != OP_LN || P.ops[ci].x != P.ops[li].y || !P.ops[ci].cw->ln_c1)
+      throw std::runtime_error("fold_ln: expected LayerNorm -> linear");
+    Op& c = P.ops[ci]; Op& l = P.ops[li];
+    c.ln_fold = true; c.x_fwd = l.x; c.ln_stats_off = l.stats_off;
+    l.ln_fold = true;
+    if (li >= 1 && !getenv("DD_NO_LN_ROWSTATS")) {
+      Op& pr = P.ops[li - 1];
+      const Tn& tx = P.t[l.x];
+      if (pr.kind == OP_CONV && pr.y == l.x && !pr.cw->geglu && !pr.cw->f32 && !pr.out_f32 && !pr.relu && pr.cw->KH == 1 && pr.cw->KW == 1 &&
+          pr.stride == 1 && !pr.up && tx.parent == l.x && !pr.part) {
+        l.rowstat_from = li - 1;
+        pr.rowstat_emit = true;
+        pr.rowstat_ld = l.rowstat_ld = (tx.C + 63) / 64;
+        P.scratch_rowpart = std::max(P.scratch_rowpart, (size_t)tx.rows * pr.rowstat_ld * 8);
+      }
+    }
   }
   // keep: the output outlives the next operation (a residual stream base, a program output)
   int ln(int x, NormW* w, float eps, bool keep = false) {
@@ -686,6 +749,7 @@ void check_transients(const Program& P) {
 void plan_gn_stats(Program& P) {
   check_transients(P);
   P.emitted.assign(P.ops.size(), 0);
+  P.row_spans.assign(P.ops.size(), 0);
   if (P.f32 || getenv("DD_NO_GN_FUSION")) return;
   std::unordered_map<int, size_t> root_part;
   for (size_t gi = 0; gi < P.ops.size(); ++gi) {
@@ -792,7 +856,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
     switch (op.kind) {
       case OP_CONV: {
         if (P.f32) { run_conv_f32_fwd(P, op, c); if (c.flops) *c.flops += op.flops; break; }
-        const Tn& x = P.t[op.x]; const Tn& y = P.t[op.y];
+        const Tn& x = P.t[op.x_fwd >= 0 ? op.x_fwd : op.x]; const Tn& y = P.t[op.y];
         ConvGemmParams p; fill_conv(p, c);
         const ConvW* w = op.cw;
         p.x = act_ptr(c, x); p.x_ld = x.ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
@@ -809,7 +873,15 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
           flags |= CF_GEGLU;
           if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
         }
+        if (op.ln_fold) { flags |= CF_LNFOLD; p.ln_stats = (const float*)(c.act + op.ln_stats_off); p.ln_c1 = w->ln_c1; }
         p.flags = flags;
+        if (op.rowstat_emit) {
+          // LayerNorm row partials for the op that follows: only when the kernel the launcher picks for this shape has the form
+          p.rowpart = c.rowpart; p.rowpart_ld = op.rowstat_ld;
+          int spans = 0;
+          if (c.rowpart && conv_gemm_can_emit_rowstats(p, c.partial_cap, &spans) && spans <= op.rowstat_ld) { p.flags |= CF_ROWSTATS; P.row_spans[i] = spans; }
+          else { p.rowpart = nullptr; P.row_spans[i] = 0; }
+        }
         if (op.use_table && c.img_bias > 0 && w->bias_table_img) {
           // SDXL text_time conditioning: the time-embedding bias differs per image -> one launch per image of the batch (B x H x W
           // rows each; at 128x128 / 64x64 / 32x32 latents an image still fills the chip), each with its own row of the bias table
@@ -870,6 +942,11 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin = 0, int op_end = -1) 
         p.x = act_ptr(c, x); p.x_ld = x.ld; p.y = act_ptr(c, y); p.y_ld = y.ld;
         p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off);
         p.M = x.rows; p.C = x.C; p.eps = op.eps;
+        if (op.ln_fold) {
+          // folded into the linear that follows: statistics only, from the producing GEMM's row partials when it emitted them
+          p.y = nullptr;
+          if (op.rowstat_from >= 0 && P.row_spans[op.rowstat_from] > 0) { p.rowpart = c.rowpart; p.rowpart_ld = op.rowstat_ld; p.spans = P.row_spans[op.rowstat_from]; }
+        }
         HIPCHK(launch_layernorm_fwd(p, c.s));
       } break;
       case OP_ATTN: {
@@ -1122,14 +1199,18 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     snprintf(tb, sizeof tb, ".transformer_blocks.%d", d);
     const std::string t = p + tb;
     // self attention (fused QKV projection, no bias)
+    // the three LayerNorms of a block are folded into the linear each of them feeds (Builder::fold_ln; DD_NO_LN_FOLD=1 builds the plain graph)
+    const bool fold = ln_fold_enabled();
     int n = b.ln(h, make_norm(E, m, t + ".norm1"), 1e-5f);
-    int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false));
+    int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false, fold ? t + ".norm1" : ""));
+    if (fold) b.fold_ln();
     int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
     int a = b.attn(q, k, v, heads, HW, HW, -1);
     h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
     // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
     n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
-    int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false));
+    int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false, fold ? t + ".norm2" : ""));
+    if (fold) b.fold_ln();
     if (P.t[q2].B == E->cfg.max_batch && b.full_batch == 2 * E->cfg.max_batch) {
       // Up to here the unconditional and the conditional half of the CFG batch were the SAME computation (same latents, same timestep;
       // only the text differs): it ran once on B images.  The first cross-attention is where they part: cat[q, q], cat[h, h].
@@ -1146,7 +1227,8 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
     // GEGLU feed-forward
     n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);
-    int ff = b.conv(n, make_conv(E, m, t + ".ff.net.0.proj", 0, true));
+    int ff = b.conv(n, make_conv(E, m, t + ".ff.net.0.proj", 0, true, true, fold ? t + ".norm3" : ""));
+    if (fold) b.fold_ln();
     h = b.conv(ff, make_conv(E, m, t + ".ff.net.2", 0), 1, 0, h);
   }
   return b.conv(h, make_conv(E, m, p + ".proj_out", 0), 1, 0, x);
@@ -1489,7 +1571,7 @@ struct Run {
   dd_engine* E; hipStream_t s; int B;
   Ctx ctx(const Program& P, char* act) {
     Ctx c; c.act = act; c.grad = E->grad_slab; c.tr = E->tr_slab; c.tr_stride = P.tr_max; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
-    c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
+    c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.rowpart = E->rowpart; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
     return c;
   }
 };
@@ -1777,6 +1859,7 @@ int dd_finalize_weights(dd_engine* E) {
     E->scratch_tmp = (char*)E->dmalloc(E->tmp_cap);
     const int maxG = std::max(c.unet_groups, c.vae_groups);
     E->gn_scratch = (float*)E->dmalloc(groupnorm_scratch_bytes(2 * B, maxG), false);
+    E->rowpart = (float*)E->dmalloc(std::max(E->unet.scratch_rowpart, (size_t)256), false);
     for (auto& f : E->f32_tmp) f = (float*)E->dmalloc(zbytes);
     E->img_tmp = (float*)E->dmalloc((size_t)B * 3 * 64 * L * L * 4);
     E->score_tmp = (float*)E->dmalloc(256);

@@ -23,8 +23,14 @@ enum ConvFlags {
   CF_RES_F32 = 64,   // residual is fp32
   CF_GEGLU_RAW = 128,// with CF_GEGLU: also store the raw packed pre-activation (bf16) to raw[m, N]
   CF_RELU6 = 512,    // min(max(., 0), 6)   (fp32 guide kernels: MobileNetV2)
-  CF_STATS = 256     // also emit per-(64-row block, output channel) partial statistics (mean, M2) of the stored values: the
+  CF_STATS = 256,    // also emit per-(64-row block, output channel) partial statistics (mean, M2) of the stored values: the
                      // GroupNorm that consumes this tensor then needs no statistics pass of its own (conv_gemm_can_emit_stats)
+  CF_LNFOLD = 1024,  // the A operand is the RAW input x of a LayerNorm whose gamma is folded into the packed weights (W' = gamma o W) and
+                     // whose beta into the bias (b' = b + W beta): out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n] with
+                     // c1[n] = sum_k W'[n, k] (of the bf16-rounded W'), (mean, rstd) = ln_stats[m] -- LayerNorm(x) W^T + b without ever
+                     // materialising LayerNorm(x).  Pointwise (1x1 / linear) layers only.
+  CF_ROWSTATS = 2048 // also emit, per output row and per 80-/64-column wave span, (sum v, sum v^2) of the stored values into rowpart: the
+                     // LayerNorm that consumes this tensor takes its row statistics from there (conv_gemm_can_emit_rowstats)
 };
 
 struct ConvGemmParams {
@@ -39,7 +45,10 @@ struct ConvGemmParams {
   bf16_t* raw;          // GEGLU raw output or null
   float* partial;       // split-K workspace [ksplit][M][N] fp32 (ksplit > 1)
   float* stats;         // CF_STATS: [M / 64][stats_ld][2] fp32 (mean, M2 of 64 rows), already offset to this op's first channel
-  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride, stats_ld;
+  const float* ln_stats;// CF_LNFOLD: [M][2] fp32 (mean, rstd) of the LayerNorm's input rows
+  const float* ln_c1;   // CF_LNFOLD: [N] fp32 column sums of the folded weights (packed order for GEGLU)
+  float* rowpart;       // CF_ROWSTATS: [M][rowpart_ld][2] fp32 (sum, sum of squares) per row and column span of conv_gemm_rowstat_span(N)
+  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride, stats_ld, rowpart_ld;
   int B, H, W;          // stored input geometry
   int Ho, Wo;           // output geometry
   int stride;           // output->logical-input stride (1 or 2)
@@ -60,6 +69,9 @@ int conv_gemm_pick_split(int M, int N, int K);
 // true iff launch_conv_gemm(p, partial_cap_bytes) will honour CF_STATS for this problem (persistent big-tile kernel, no split-K,
 // M % 64 == 0, plain bf16 output): the caller asks before setting the flag and falls back to the GroupNorm statistics pass otherwise
 bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes);
+// CF_ROWSTATS: true iff launch_conv_gemm will honour it for this problem; *spans = number of (sum, sum^2) pairs per row it writes
+// (N / columns per wave of the tile the launcher picks); rowpart_ld must be >= *spans
+bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int* spans);
 
 // ----------------------------------------------------------------------------------------------
 // K3: GroupNorm (+ optional SiLU) forward / backward on NHWC bf16.
@@ -93,6 +105,8 @@ struct LayerNormParams {
   const float* gamma; const float* beta;
   float* stats;        // [M][2] mean, rstd
   int M, C; float eps;
+  const float* rowpart; int rowpart_ld, spans;   // fwd, y == null: statistics only -- from the producing GEMM's row partials when given
+                                                 // ([M][rowpart_ld][2] (sum, sum^2) over `spans` column spans), else from x
   const bf16_t* dy; int dy_ld;
   bf16_t* dx; int dx_ld;
   int accumulate;

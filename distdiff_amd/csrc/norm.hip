@@ -313,11 +313,12 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(LayerNormParams p) {
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
   if (row0 >= p.M) return;
   const int VC = p.C >> 3;
+  const bool stats_only = p.y == nullptr;     // the LayerNorm is folded into the GEMM that follows (CF_LNFOLD): statistics only
   float ga[VI][8], be[VI][8];
 #pragma unroll
   for (int i = 0; i < VI; ++i) {
     const int vc = lane + 64 * i;
-    if (vc < VC) {
+    if (vc < VC && !stats_only) {
       const float4 g0 = *(const float4*)(p.gamma + vc * 8), g1 = *(const float4*)(p.gamma + vc * 8 + 4);
       const float4 b0 = *(const float4*)(p.beta + vc * 8), b1 = *(const float4*)(p.beta + vc * 8 + 4);
       ga[i][0] = g0.x; ga[i][1] = g0.y; ga[i][2] = g0.z; ga[i][3] = g0.w; ga[i][4] = g1.x; ga[i][5] = g1.y; ga[i][6] = g1.z; ga[i][7] = g1.w;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(LayerNormParams p) {
       }
     const float rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
     if (lane == 0 && p.stats) { p.stats[(size_t)row * 2] = mean; p.stats[(size_t)row * 2 + 1] = rstd; }
+    if (stats_only) continue;
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
       const int vc = lane + 64 * i;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LayerNormParams p) {
     }
     rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
     if (lane == 0 && p.stats) { p.stats[(size_t)row * 2] = mean; p.stats[(size_t)row * 2 + 1] = rstd; }
+    if (p.y == nullptr) return;               // statistics only (the LayerNorm is folded into the GEMM that follows)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vc = lane + 64 * i;
@@ -502,8 +505,29 @@ hipError_t launch_groupnorm_bwd(const GroupNormParams& p, hipStream_t stream) {
   return gn_launch<true>(p, stream);
 }
 
+// (mean, rstd) of every row from the (sum, sum^2) partials the producing GEMM emitted per column span (CF_ROWSTATS): M x spans x 8 bytes
+// read instead of the M x C x 2 of a pass over the tensor.  fp32 sums of the fp32 values in front of their bf16 rounding.
+__global__ __launch_bounds__(256) void ln_rowpart_finalize_kernel(LayerNormParams p) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.M) return;
+  const float2* pp = (const float2*)p.rowpart + (size_t)row * p.rowpart_ld;
+  float a = 0.f, q = 0.f;
+  for (int s = 0; s < p.spans; ++s) { const float2 v = pp[s]; a += v.x; q += v.y; }
+  const float mean = a / p.C;
+  const float var = fmaxf(q / p.C - mean * mean, 0.f);
+  *(float2*)(p.stats + (size_t)row * 2) = make_float2(mean, rsqrtf(var + p.eps));
+}
+
 hipError_t launch_layernorm_fwd(const LayerNormParams& p, hipStream_t stream) {
-  if (p.C % 8 || p.C > 2048 || (p.x_ld & 7) || (p.y_ld & 7)) return hipErrorInvalidValue;
+  if (p.C % 8 || p.C > 2048 || (p.x_ld & 7) || (p.y && (p.y_ld & 7))) return hipErrorInvalidValue;
+  if (!p.y) {
+    if (!p.stats) return hipErrorInvalidValue;
+    if (p.rowpart) {
+      if (p.spans < 1 || p.rowpart_ld < p.spans) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(ln_rowpart_finalize_kernel, dim3((p.M + 255) / 256), dim3(256), 0, stream, p);
+      return hipGetLastError();
+    }
+  }
   static const int rows_kernel = getenv("DD_LN_ROWS") ? atoi(getenv("DD_LN_ROWS")) : 1;   // A/B switch
   if (rows_kernel && p.C <= 1536) {
     const int vi = (p.C / 8 + 63) / 64;

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, CF_STATS, AttnParams,
+from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_LNFOLD, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, CF_ROWSTATS, CF_STATS, AttnParams,
                    ConvGemmParams, GroupNormParams, LayerNormParams, check)
 
 
@@ -101,7 +101,8 @@ def conv_f32(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask
 
 
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
-              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False, stats=None):
+              ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False, stats=None, ln_stats=None, ln_c1=None,
+              rowpart=None):
     """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)].  stats: fp32 [M/64, C, 2] buffer (or a column view of one) to
     receive the per-(64-row block, channel) partial (mean, M2) of the stored values (CF_STATS; the launch fails if the kernel the
     launcher picks for this shape cannot emit them)."""
@@ -145,6 +146,12 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
     if stats is not None:
         flags |= CF_STATS
         p.stats, p.stats_ld = _ptr(stats), stats.stride(0) // 2
+    if ln_stats is not None:      # CF_LNFOLD: x is the raw LayerNorm input, pk holds gamma o W, ln_c1 its column sums (packed order)
+        flags |= CF_LNFOLD
+        p.ln_stats, p.ln_c1 = _ptr(ln_stats), _ptr(ln_c1)
+    if rowpart is not None:       # CF_ROWSTATS: fp32 [M, spans, 2] (sum, sum of squares) per row and column span
+        flags |= CF_ROWSTATS
+        p.rowpart, p.rowpart_ld = _ptr(rowpart), rowpart.stride(0) // 2
     p.ksplit, p.flags, p.alpha = ksplit, flags, alpha
     p.force_small = int(force_small)
     check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
@@ -171,6 +178,18 @@ def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None, chan_par
     p.dy, p.dy_ld, p.dx, p.dx_ld, p.accumulate = _ptr(dy), dy.stride(0), _ptr(dx), dx.stride(0), 0
     check(L.dd_op_groupnorm_bwd(C.byref(p), _stream()), "gn_bwd")
     return dx
+
+
+def layernorm_stats(x, eps, rowpart=None, spans=0):
+    """(mean, rstd) [M, 2] only (a LayerNorm folded into the GEMM that follows): from x, or from a GEMM's row partials."""
+    M, Cc = x.shape
+    p = LayerNormParams()
+    stats = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+    p.x, p.x_ld, p.stats, p.M, p.C, p.eps = _ptr(x), x.stride(0), _ptr(stats), M, Cc, eps
+    if rowpart is not None:
+        p.rowpart, p.rowpart_ld, p.spans = _ptr(rowpart), rowpart.stride(0) // 2, spans
+    check(_lib.lib().dd_op_layernorm_fwd(C.byref(p), _stream()), "ln_stats")
+    return stats
 
 
 def layernorm(x, gamma, beta, eps, dy=None, stats=None):

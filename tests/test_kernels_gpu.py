@@ -248,6 +248,59 @@ def test_layernorm(ops, Cc):
     assert_close(dx, gx, rtol=2e-2, atol=2e-3, what="ln bwd")
 
 
+@pytest.mark.parametrize("M,Cc,N,geglu", [(4096, 320, 960, False), (2048, 640, 640, False), (4096, 320, 2560, True), (300, 320, 320, False),
+                                            (1024, 1280, 3840, False)])
+def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
+    """CF_LNFOLD: LayerNorm(x) W^T + b computed as rstd * (x (gamma o W)^T - mean * c1) + (b + W beta) from the RAW x and the row
+    statistics -- the transformer blocks' LayerNorm -> QKV / to_q / GEGLU projections (diffusers BasicTransformerBlock).
+    Checked against torch's layer_norm + linear on the same bf16 inputs (the folded form never rounds LayerNorm(x) to bf16, so it is
+    the more accurate of the two); M = 300 takes the small kernel's generic epilogue, the others the batched two-workgroup forms."""
+    g = torch.Generator().manual_seed(77)
+    x = bf(torch.randn(M, Cc, generator=g) * 1.7 + torch.randn(M, 1, generator=g) * 0.8)      # row means of the size of the row std
+    gamma, beta = 1.0 + 0.3 * torch.randn(Cc, generator=g), 0.2 * torch.randn(Cc, generator=g)
+    w = torch.randn(N, Cc, generator=g) / math.sqrt(Cc)
+    bias = torch.randn(N, generator=g)
+    ref = F.linear(F.layer_norm(x, (Cc,), gamma, beta, 1e-5), bf(w), bias)
+    if geglu:
+        hh, gg = ref.chunk(2, dim=-1)
+        ref = hh * F.gelu(gg)
+    wf = bf(w * gamma[None, :])
+    bfold = bias + bf(w) @ beta
+    pk = ops.PackedConv(wf, 0, geglu=geglu, bias=bfold)
+    pc = ops.PackedConv(wf, 0, geglu=geglu, bias=wf.sum(dim=1))          # c1 in the packed column order (reuses the bias permutation)
+    xd = x.to(torch.bfloat16).cuda()
+    stats = ops.layernorm_stats(xd, 1e-5)
+    mu, var = x.mean(1), x.var(1, unbiased=False)
+    assert_close(stats[:, 0], mu, rtol=1e-4, atol=1e-5, what="ln mean")
+    assert_close(stats[:, 1], (var + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5, what="ln rstd")
+    y = ops.conv_gemm(xd, pk, 1, M, 1, M, 1, ksplit=1, ln_stats=stats, ln_c1=pc.bias)
+    torch.cuda.synchronize()
+    assert_close(y, ref, rtol=1.5e-2, atol=2e-2, what="ln-folded linear")
+
+
+@pytest.mark.parametrize("M,K,N", [(16384, 320, 320), (8192, 1280, 640), (3000, 640, 1280)])
+def test_linear_emits_layernorm_row_partials(ops, M, K, N):
+    """CF_ROWSTATS: the to_out / ff.net.2 / proj_in GEMMs emit (sum, sum^2) of every output row per 80-column wave span; the LayerNorm
+    that follows finalises (mean, rstd) from them instead of reading the tensor."""
+    g = torch.Generator().manual_seed(78)
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    res = bf(torch.randn(M, N, generator=g) * 2.0 + 0.5)
+    pk = ops.PackedConv(w, 0, bias=bias)
+    spans = N // 80
+    part = torch.zeros((M, spans, 2), device="cuda", dtype=torch.float32)
+    y = ops.conv_gemm(x.to(torch.bfloat16).cuda(), pk, 1, M, 1, M, 1, res=res.to(torch.bfloat16).cuda(), ksplit=1, rowpart=part)
+    torch.cuda.synchronize()
+    ref = x @ w.t() + bias + res
+    assert_close(y, ref, what="rowstats: output")
+    assert_close(part[:, :, 0].sum(1), ref.sum(1), rtol=2e-3, atol=2e-2, what="row sums")
+    assert_close(part[:, :, 1].sum(1), (ref * ref).sum(1), rtol=2e-3, atol=2e-2, what="row sums of squares")
+    stats = ops.layernorm_stats(y, 1e-5, rowpart=part, spans=spans)
+    assert_close(stats[:, 0], ref.mean(1), rtol=2e-3, atol=2e-3, what="mean from partials")
+    assert_close(stats[:, 1], (ref.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=4e-3, atol=1e-4, what="rstd from partials")
+
+
 ATT_CASES = [("self_d40", 2, 8, 256, 256, 40), ("self_d64", 1, 2, 200, 200, 64), ("self_d80", 1, 4, 128, 128, 80),
              ("self_d160", 1, 2, 64, 64, 160), ("cross77_d40", 2, 8, 256, 77, 40), ("cross77_d160", 1, 8, 64, 77, 160),
              ("self_d32", 1, 2, 96, 96, 32), ("vae_d512", 1, 1, 256, 256, 512)]
