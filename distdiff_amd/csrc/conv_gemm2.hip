@@ -78,7 +78,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   // at most two items ahead of the epilogue), read from LDS by the batched epilogue -- a global load there costs an exposed L2 / HBM
   // latency per item (tools/conv_trace.py: 3 us of epilogue on a 5-step item, half of it the bias wait)
   constexpr int BIAS_OFF = NS * BUF_BYTES + 256;
-  constexpr int C1_OFF = BIAS_OFF + 3 * 1024;     // ST == 3: column sums of the LayerNorm-folded weights, same ring discipline
+  // ST == 3: column sums of the LayerNorm-folded weights and the (mean, rstd) of the item's BM = 128 rows (1 KB each) arrive the same
+  // way; two slots each: with K >= 192 (three K-steps per item, checked by the host) the two-stage loader reaches item w + 2 only
+  // after the epilogue of item w has run
+  constexpr int C1_OFF = BIAS_OFF + 3 * 1024;
+  constexpr int LNS_OFF = C1_OFF + 2 * 1024;
+  static_assert(ST != 3 || (NS == 2 && BM == 128), "LayerNorm-fold form: two-stage 128-row tiles only");
+  int l_slot2 = 0, c_slot2 = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -187,7 +193,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       dma16(bias, smem + BIAS_OFF + l_slot * 1024, voff, 0);
       if constexpr (ST == 3) {
         const unsigned v1 = (lane * 4 < BN && nb + 4 <= p.N) ? (unsigned)nb * 4u : OOB;
-        dma16(p.ln_c1, smem + C1_OFF + l_slot * 1024, v1, 0);
+        dma16(p.ln_c1, smem + C1_OFF + l_slot2 * 1024, v1, 0);
+        const int mr = m0 + lane * 2;                                   // 16 bytes = (mean, rstd) of two rows
+        dma16(p.ln_stats, smem + LNS_OFF + l_slot2 * 1024, mr + 2 <= p.M ? (unsigned)mr * 8u : OOB, 0);
+        l_slot2 ^= 1;
       }
       l_slot = l_slot == 2 ? 0 : l_slot + 1;
     }
@@ -385,7 +394,50 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     // (a CF_LNFOLD launch that did not get its ST == 3 instantiation -- an eight-wave or general-staging form -- takes the generic
     //  epilogue below, whose Epi::apply folds from global memory)
     const bool fold_ok = ST == 3 || !(fl & CF_LNFOLD);
-    if (fold_ok && tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
+    if constexpr (ST == 3) {
+      // LayerNorm folded into this linear (QKV / to_q of a transformer block): out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n].  No
+      // residual, no activation; tile pairs in the outer loop so that only one pair's bias / c1 vectors are live at a time.
+      if (tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES | CF_RES_F32 | CF_OUT_F32 | CF_RELU))) {
+        const int wb = n0 + wn * (TN * 16);
+        const int cp = wb + fq * 8, co = wb + (TN - 1) * 16 + fq * 4;
+        float rs[TM], nm[TM];                     // rstd and -rstd * mean of this lane's rows
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float2 st = *(const float2*)(smem + LNS_OFF + c_slot2 * 1024 + (wm * (TM * 16) + i * 16 + fr) * 8);
+          rs[i] = st.y * p.alpha; nm[i] = -st.y * st.x;
+        }
+        auto four = [&](const f32x4& a, const float4& b, const float4& c, int i) {
+          const float v0 = __builtin_fmaf(rs[i], a[0], __builtin_fmaf(nm[i], c.x, b.x)), v1 = __builtin_fmaf(rs[i], a[1], __builtin_fmaf(nm[i], c.y, b.y));
+          const float v2 = __builtin_fmaf(rs[i], a[2], __builtin_fmaf(nm[i], c.z, b.z)), v3 = __builtin_fmaf(rs[i], a[3], __builtin_fmaf(nm[i], c.w, b.w));
+          return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        };
+        const unsigned char* bl = smem + BIAS_OFF + c_slot * 1024 + (wn * (TN * 16)) * 4;
+        const unsigned char* cl = smem + C1_OFF + c_slot2 * 1024 + (wn * (TN * 16)) * 4;
+#pragma unroll
+        for (int t = 0; t < TN / 2; ++t) {
+          const float4 b0 = *(const float4*)(bl + col_of(2 * t) * 4), b1 = *(const float4*)(bl + col_of(2 * t + 1) * 4);
+          const float4 c0 = *(const float4*)(cl + col_of(2 * t) * 4), c1 = *(const float4*)(cl + col_of(2 * t + 1) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+            if (m >= p.M) continue;
+            const uint2 lo = four(acc[2 * t][i], b0, c0, i), hi = four(acc[2 * t + 1][i], b1, c1, i);
+            *(uint4*)((bf16_t*)p.y + (size_t)m * p.y_ld + cp + 32 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        }
+        if constexpr (TN & 1) {
+          const float4 b0 = *(const float4*)(bl + col_of(TN - 1) * 4), c0 = *(const float4*)(cl + col_of(TN - 1) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+            if (m >= p.M) continue;
+            *(uint2*)((bf16_t*)p.y + (size_t)m * p.y_ld + co) = four(acc[TN - 1][i], b0, c0, i);
+          }
+        }
+        return;
+      }
+    }
+    if (ST != 3 && fold_ok && tile_full && !(fl & (CF_GEGLU | CF_MASK | CF_RES_F32 | CF_OUT_F32)) && (!(fl & CF_RES) || !(p.res_ld & 7))) {
       // 16-byte loads / stores per tile pair; bias and every residual row are requested before the first use.  (Keeping the
       // bias in registers from the start of the item was measured slower: 20 VGPRs live across the K loop, tools/ab_ops.sh.)
       const int wb = n0 + wn * (TN * 16);
@@ -412,16 +464,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
       }
-      // ST == 3: LayerNorm folded into this GEMM: out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n]; ST == 2: per-row (sum, sum^2)
-      float4 cv[ST == 3 ? TN : 1];
-      float2 lnst[ST == 3 ? TM : 1];
-      float rs1[ST == 2 ? TM : 1], rs2[ST == 2 ? TM : 1];
-      if constexpr (ST == 3) {
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) cv[jn] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (wn * (TN * 16) + col_of(jn)) * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) lnst[i] = *(const float2*)(p.ln_stats + (size_t)min(m0 + wm * (TM * 16) + i * 16 + fr, p.M - 1) * 2);
-      }
+      float rs1[ST == 2 ? TM : 1], rs2[ST == 2 ? TM : 1];     // ST == 2: per-row (sum, sum^2) of the stored values
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
@@ -429,14 +472,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
         if (m >= p.M) continue;
         bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
         auto four = [&](const f32x4& a, const float4& b, unsigned r0, unsigned r1, float* t1, float* t2, int jn) {
-          float v0, v1, v2, v3;
-          if constexpr (ST == 3) {
-            const float mu = lnst[i].x, rs = lnst[i].y;
-            v0 = __builtin_fmaf(rs, a[0] * p.alpha - mu * cv[jn].x, b.x); v1 = __builtin_fmaf(rs, a[1] * p.alpha - mu * cv[jn].y, b.y);
-            v2 = __builtin_fmaf(rs, a[2] * p.alpha - mu * cv[jn].z, b.z); v3 = __builtin_fmaf(rs, a[3] * p.alpha - mu * cv[jn].w, b.w);
-          } else {
-            v0 = a[0] * p.alpha + b.x; v1 = a[1] * p.alpha + b.y; v2 = a[2] * p.alpha + b.z; v3 = a[3] * p.alpha + b.w;
-          }
+          (void)jn;
+          float v0 = a[0] * p.alpha + b.x, v1 = a[1] * p.alpha + b.y, v2 = a[2] * p.alpha + b.z, v3 = a[3] * p.alpha + b.w;
           if (fl & CF_RES) {
             v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
             v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
@@ -481,19 +518,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       if (fold_ok && tile_full && (fl & CF_GEGLU) && !(fl & (CF_MASK | CF_RES | CF_OUT_F32)) && !(p.raw_ld & 3)) {
         float4 bh[TN / 2], bg[TN / 2];
         float4 ch[ST == 3 ? TN / 2 : 1], cg[ST == 3 ? TN / 2 : 1];
-        float2 lnst[ST == 3 ? TM : 1];
+        float rs[ST == 3 ? TM : 1], nm[ST == 3 ? TM : 1];      // ST == 3: rstd and -rstd * mean of this lane's rows
 #pragma unroll
         for (int t = 0; t < TN / 2; ++t) {
           bh[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
           bg[t] = *(const float4*)(smem + BIAS_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
           if constexpr (ST == 3) {
-            ch[t] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
-            cg[t] = *(const float4*)(smem + C1_OFF + c_slot * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
+            ch[t] = *(const float4*)(smem + C1_OFF + c_slot2 * 1024 + (ncol0 - n0 + 2 * t * 16) * 4);
+            cg[t] = *(const float4*)(smem + C1_OFF + c_slot2 * 1024 + (ncol0 - n0 + 2 * t * 16 + 16) * 4);
           }
         }
         if constexpr (ST == 3) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) lnst[i] = *(const float2*)(p.ln_stats + (size_t)min(m0 + wm * (TM * 16) + i * 16 + fr, p.M - 1) * 2);
+          for (int i = 0; i < TM; ++i) {
+            const float2 st = *(const float2*)(smem + LNS_OFF + c_slot2 * 1024 + (wm * (TM * 16) + i * 16 + fr) * 8);
+            rs[i] = st.y * p.alpha; nm[i] = -st.y * st.x;
+          }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -504,11 +544,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
             const int nb = ncol0 + 2 * t * 16;
             float h0, h1, h2, h3, g0, g1, g2, g3;
             if constexpr (ST == 3) {
-              const float mu = lnst[i].x, rs = lnst[i].y;
-              h0 = __builtin_fmaf(rs, acc[2 * t][i][0] * p.alpha - mu * ch[t].x, bh[t].x); h1 = __builtin_fmaf(rs, acc[2 * t][i][1] * p.alpha - mu * ch[t].y, bh[t].y);
-              h2 = __builtin_fmaf(rs, acc[2 * t][i][2] * p.alpha - mu * ch[t].z, bh[t].z); h3 = __builtin_fmaf(rs, acc[2 * t][i][3] * p.alpha - mu * ch[t].w, bh[t].w);
-              g0 = __builtin_fmaf(rs, acc[2 * t + 1][i][0] * p.alpha - mu * cg[t].x, bg[t].x); g1 = __builtin_fmaf(rs, acc[2 * t + 1][i][1] * p.alpha - mu * cg[t].y, bg[t].y);
-              g2 = __builtin_fmaf(rs, acc[2 * t + 1][i][2] * p.alpha - mu * cg[t].z, bg[t].z); g3 = __builtin_fmaf(rs, acc[2 * t + 1][i][3] * p.alpha - mu * cg[t].w, bg[t].w);
+              // LayerNorm folded into the GEGLU projection: rstd * (acc - mean * c1) + b' on both halves
+              h0 = __builtin_fmaf(rs[i], acc[2 * t][i][0], __builtin_fmaf(nm[i], ch[t].x, bh[t].x)); h1 = __builtin_fmaf(rs[i], acc[2 * t][i][1], __builtin_fmaf(nm[i], ch[t].y, bh[t].y));
+              h2 = __builtin_fmaf(rs[i], acc[2 * t][i][2], __builtin_fmaf(nm[i], ch[t].z, bh[t].z)); h3 = __builtin_fmaf(rs[i], acc[2 * t][i][3], __builtin_fmaf(nm[i], ch[t].w, bh[t].w));
+              g0 = __builtin_fmaf(rs[i], acc[2 * t + 1][i][0], __builtin_fmaf(nm[i], cg[t].x, bg[t].x)); g1 = __builtin_fmaf(rs[i], acc[2 * t + 1][i][1], __builtin_fmaf(nm[i], cg[t].y, bg[t].y));
+              g2 = __builtin_fmaf(rs[i], acc[2 * t + 1][i][2], __builtin_fmaf(nm[i], cg[t].z, bg[t].z)); g3 = __builtin_fmaf(rs[i], acc[2 * t + 1][i][3], __builtin_fmaf(nm[i], cg[t].w, bg[t].w));
             } else {
               h0 = acc[2 * t][i][0] * p.alpha + bh[t].x; h1 = acc[2 * t][i][1] * p.alpha + bh[t].y;
               h2 = acc[2 * t][i][2] * p.alpha + bh[t].z; h3 = acc[2 * t][i][3] * p.alpha + bh[t].w;
@@ -645,6 +685,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 #endif
     epilogue(cw);
     c_slot = c_slot == 2 ? 0 : c_slot + 1;
+    if constexpr (ST == 3) c_slot2 ^= 1;
 #ifdef DD_TRACE
     trace_stamp(tn, 2);
 #endif
@@ -662,7 +703,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
 template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM, int ST>
 hipError_t run_big_fe3(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = NS * (BM + BN) * 128 + 256 + (ST == 3 ? 6 : 3) * 1024;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets), bias (+ c1) ring
+  constexpr int lds = NS * (BM + BN) * 128 + 256 + (ST == 3 ? 7 : 3) * 1024;   // + per-tap tables (<= 32 taps: packed (dy,dx) and byte offsets), bias (+ c1) ring
   static_assert(lds <= 163840, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_gemm_big_kernel<WM, WN, TM, TN, NS, FE, FM, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -676,7 +717,7 @@ template <int WM, int WN, int TM, int TN, int NS, bool FE, int FM>
 hipError_t run_big_fe2(const ConvGemmParams& p, hipStream_t stream) {
   // the LayerNorm forms only exist for the batched epilogue of the two-workgroup (shallow-K, pointwise) tiles: conv_gemm_ln_form()
   if constexpr (WM * WN == 4 && FE && FM == 1) {
-    if (p.flags & CF_LNFOLD) return run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 3>(p, stream);
+    if ((p.flags & CF_LNFOLD) && p.K >= 192 && !(p.M & 1)) return run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 3>(p, stream);
     if (p.flags & CF_ROWSTATS) return run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 2>(p, stream);
   }
   return (p.flags & CF_STATS) ? run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 1>(p, stream) : run_big_fe3<WM, WN, TM, TN, NS, FE, FM, 0>(p, stream);
