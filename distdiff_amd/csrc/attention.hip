@@ -95,8 +95,22 @@ constexpr float LOG2E = 1.4426950408889634f;
 // forward.  grid (ceil(Nq / QB), H, B), 256 threads. DSPLIT=1: each wave owns QT 16-query tiles;
 // DSPLIT=4: the 4 waves share one set of QT tiles and each accumulates a quarter of the head dim (d=512).
 // ------------------------------------------------------------------------------------------------
+// Minimum waves per SIMD asked of the register allocator (the second __launch_bounds__ argument), per head dim.  The kernels wait on
+// LDS / barriers / exp latency with 2-3 waves per SIMD; one more resident wave is worth more than the few registers it spills
+// (tools/bench_attn_occ.py, same device: d = 40 forward 1612 -> 1527 us at 4 waves / 128 VGPRs with 7 spilled registers; d = 80
+// 397 -> 327 us at 3 waves / 168 VGPRs, its 77-key cross-attention 91 -> 82 us; NOT for d = 64 at 4 waves (48 spills: 1190 -> 1910 us),
+// d = 40 at 5 waves (3x slower) or the backward kernels at 3 waves (d = 40: 1620 -> 1680 us)).
+#ifndef DD_AW_FWD
+#define DD_AW_FWD(D) ((D) <= 40 ? 4 : (D) <= 80 ? 3 : 1)
+#endif
+#ifndef DD_AW_DQ
+#define DD_AW_DQ(D) 1
+#endif
+#ifndef DD_AW_DKV
+#define DD_AW_DKV(D) 1
+#endif
 template <int D, int QT, int KT, int DSPLIT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
   constexpr int DVT = (D + 15) / 16;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 //   dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T dS^T
 // ------------------------------------------------------------------------------------------------
 template <int D, int QT, int KT, int DSPLIT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
   constexpr int DVT = (D + 15) / 16;
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ------------------------------------------------------------------------------------------------
 template <int D, int KTW, int QTL, int DSPLIT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DD_AW_DKV(D)) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
   constexpr int DVT = (D + 15) / 16;

@@ -1,0 +1,60 @@
+"""BASELINE.json configs[4] at FULL size: the SDXL-base UNet (320 / 640 / 1280 wide, transformer depths 1 / 2 / 10, heads 5 / 10 / 20,
+cross_attention_dim 2048, text_time conditioning) at 128x128 latents = 1024x1024 images, B = 1, through the production C ABI against
+the fp32 CPU oracle's outputs committed as tests/golden/sdxl_fixture.pt (tests/golden/make_sdxl_fixture.py: forward + torch.autograd
+VJP; inputs and weights are regenerated here from the same seeds).  The reference cannot run this model: the oracle
+restates the published diffusers UNet2DConditionModel / AutoencoderKL.
+
+Tolerances (relative L2, bf16 storage + bf16 MFMA inputs + fp32 accumulation vs fp32): eps2 / z_next / x0 / decoded image <= 3 %,
+UNet VJP with a random cotangent <= 5 % -- the SD-1.5 full-size tolerances of tests/test_fullsize_gpu.py.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    assert torch.isfinite(a).all()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_sdxl_base_unet_step_vjp_and_1024_decode(hip_lib):
+    from make_sdxl_fixture import inputs
+    from distdiff_amd.config import sdxl_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90e9:
+        pytest.skip("the SDXL engine at 1024x1024 with its reverse programs needs ~70 GB of HBM")
+    fx = torch.load(os.path.join(HERE, "golden", "sdxl_fixture.pt"), weights_only=False)
+    cfg = sdxl_config(latent_size=128, max_batch=1)
+    w = synthetic_weights(cfg, seed=0, num_classes=100)
+    chk = float(sum(v.double().sum() for v in w["unet"].values()))
+    assert abs(chk - fx["weights_checksum"]) <= 1e-6 * abs(fx["weights_checksum"]), "synthetic weights differ from the fixture's"
+    eng = Engine(cfg, w, enable_grad=True, max_guidance_period=1)
+    del w
+    try:
+        sched = DDIMSchedule(cfg.scheduler)
+        ts = sched.set_timesteps(50)
+        si = fx["step_index"]
+        assert int(ts[si]) == fx["t"]
+        eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=7.5, guidance_period=1)
+        d = inputs(cfg)
+        eng.set_prompt(torch.cat([d["neg"], d["pos"]]).cuda())
+        eng.set_added_cond(d["te"], d["ti"])
+        e = (rel(eng.unet_forward(d["z"], si), fx["eps2"]),)
+        zp, x0 = eng.denoise_step(d["z"], si)
+        e += (rel(zp, fx["z_next"]), rel(x0, fx["x0"]))
+        e += (rel(eng.unet_vjp(d["z"], si, d["gg"]), fx["unet_vjp"]),)
+        e += (rel(eng.decode(fx["x0"], denormalize=False), fx["image_f16"].float()),)
+        print("SDXL-base 1024x1024: eps2 %.4f z_next %.4f x0 %.4f unet_vjp %.4f image %.4f" % e)
+        assert e[0] < 0.03 and e[1] < 0.03 and e[2] < 0.03 and e[3] < 0.05 and e[4] < 0.03, e
+    finally:
+        eng.close()
