@@ -1,0 +1,286 @@
+// K1 (deep 3x3 shapes) -- implicit-GEMM 3x3 / stride-1 / pad-1 convolution (forward and input-gradient) with a HALO-resident input
+// tile and a phase-alternating ("ping-pong") K loop, bf16 MFMA, gfx950.  Same packed weights, tap tables, NHWC row layout and epilogue
+// semantics (bias / residual / ReLU / CF_STATS GroupNorm partials) as conv_gemm2.hip; launch_conv_gemm sends eligible shapes here.
+//
+// Why (profiles/r03_gemm_schedule_micro.txt): on a CU the LDS-DMA operand stream and the MFMA stream do not overlap
+// to their individual rates -- a K-step costs about delivery time + MFMA time in every schedule tried -- so the lever is bytes per FLOP:
+//   * the nine taps of a 64-channel chunk read the SAME input pixels shifted by (dy, dx): the tile's 256 output pixels (256 / W image
+//     rows) plus a one-pixel border -- (R + 2) x (W + 2) pixels x 128 B -- are staged ONCE per chunk, zero-filled outside the image by
+//     the buffer load's range check, and the A fragments of tap (dy, dx) are read at pixel + dy * (W + 2) + dx.  Input traffic per
+//     K-step falls from 32 KB to ~5.6 KB; only the weights stream every K-step;
+//   * 256 x 320 (or 256 x 256) tiles, 8 waves as 2 (M) x 4 (N), wave tile 128 x 80: 40 KB of weights per 10.5 MFLOP K-step;
+//   * the two waves of a SIMD (row halves wr = 0 / 1) run the same program one s_barrier apart: between two barriers one issues the
+//     4 * TN MFMAs of a 32-row strip while the other reads fragments and issues its share of the next K-step's weight DMA
+//     (cdna_hip_programming.md section 5, "The 256^2 8-phase template"; MI355X_MICROARCH.md "Two waves per SIMD").
+// Not persistent: one workgroup per tile, XCD-aware tile order (n-tiles fastest inside an XCD).
+#include <cstdlib>
+#include "common.h"
+#include "kernels.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+__device__ __forceinline__ void hdma16(const void* base, void* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffff00u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+template <int CTRL>
+__device__ __forceinline__ float hdpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float hrow16_sum(float v) {
+  v = hdpp_add<0xB1>(v); v = hdpp_add<0x4E>(v); v = hdpp_add<0x141>(v); v = hdpp_add<0x140>(v);
+  return v;
+}
+
+template <int TN>
+__global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int lw, int halo_px) {
+  constexpr int BM = 256, BN = 4 * TN * 16;
+  constexpr int WB = BN * 128;                          // bytes of one weight stage
+  constexpr unsigned OOB = 0xfffffff0u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const halo = smem + 2 * WB;
+  float* const bias_s = (float*)(halo + ((halo_px + 7) & ~7) * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int Wd = 1 << lw, W2 = Wd + 2;
+
+  // ---- tile of this workgroup (n-tiles fastest; blocks b, b + 8, ... share an XCD)
+  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
+  int tile;
+  {
+    const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int HW = p.H * p.W;
+  const int img = m0 / HW, y0 = (m0 - img * HW) >> lw;  // first image row of the tile (tiles are whole image rows)
+  const int chunks = p.cin >> 6, KT = chunks * 9;
+
+  // ---- per-tap offsets: lane t holds tap t ((dy + 32) << 6 | (dx + 32)); read with readlane where needed
+  const int v_taps = lane < 9 ? p.taptab[lane] : 0;
+  if (tid < BN) bias_s[tid] = (p.flags & CF_BIAS) ? p.bias[n0 + tid] : 0.f;
+
+  // ---- weight staging: wave w moves pieces w, w + 8, ... (8 rows x 128 B) of the BN weight rows of a K-step.  LDS row R of a wave's
+  // TN * 16 span holds output channel chan_of_row(R): tiles are paired so that a lane's 4 + 4 accumulator rows of a pair are 8
+  // consecutive channels (16-byte epilogue stores), exactly as in conv_gemm2.hip.
+  const int prow = lane >> 3, jw = (lane & 7) ^ prow;
+  constexpr int TNP = TN & ~1;
+  unsigned woff[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int R = (wave + 8 * i) * 8 + prow;
+    const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
+    const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
+    woff[i] = ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u;
+  }
+  auto issue_w = [&](int kt, int i) {
+    hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)kt * 128u);
+  };
+  // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
+  const float inv_w2 = 1.f / (float)W2;
+  auto issue_halo = [&](int chunk) {
+    const int npc = (halo_px + 7) >> 3;
+    for (int pc = wave; pc < npc; pc += 4) {
+      const int hp = pc * 8 + prow;
+      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+      const int iy = y0 - 1 + hy, ix = hx - 1;
+      const bool ok = hp < halo_px && iy >= 0 && iy < p.H && ix >= 0 && ix < Wd;
+      const int j = (lane & 7) ^ (hx & 7);
+      const unsigned voff = ok ? ((unsigned)((img * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+      hdma16(p.x, halo + pc * 1024, voff, (unsigned)chunk * 128u);
+    }
+  };
+
+  f32x4 acc[8][TN];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue
+  if (wr == 0) issue_halo(0);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) issue_w(0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                      // also publishes bias_s
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
+
+  bf16x8 wf[TN][2], xf[2][2];
+  int kt = 0;
+  for (int c = 0; c < chunks; ++c) {
+    if (c > 0) {
+      // every read of the previous chunk's halo has retired (both halves waited lgkmcnt(0) in front of their last X barrier)
+      if (wr == 0) { issue_halo(c); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+    }
+    for (int t = 0; t < 9; ++t, ++kt) {
+      const int e = __builtin_amdgcn_readlane(v_taps, t);
+      const int dy = ((e >> 6) & 63) - 32, dx = (e & 63) - 32;
+      const int tapoff = dy * W2 + dx;
+      const unsigned char* Bb = smem + (kt & 1) * WB;
+      const bool more = kt + 1 < KT;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                     // 32-row strips of this wave's 128 rows
+        // ---- load section (the SIMD partner is in its MFMA section)
+        if (s == 0) {
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int row = wc * (TN * 16) + jn * 16 + fr;
+              wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wr * 128 + s * 32 + i * 16 + fr;
+          const int hp = r + 2 * (r >> lw) + Wd + 3 + tapoff;          // halo pixel of output pixel r for this tap
+          const int xs = ((r & (Wd - 1)) + 1 + dx) & 7;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) xf[i][ks] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xs) << 4));
+        }
+        if (s < 3 && more) {
+          constexpr int PP = (TN + 2) / 3;
+#pragma unroll
+          for (int q = 0; q < PP; ++q)
+            if (s * PP + q < TN) issue_w(kt + 1, s * PP + q);
+        }
+        // last strip: this wave's weight pieces of K-step kt + 1 have landed and its LDS reads of this stage (and, on tap 8, of the
+        // halo) have retired BEFORE the barrier behind which the other half reads the new stage / the halo is refilled
+        if (s == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- MFMA section
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // balance the barrier count of the two halves
+
+  // ---- epilogue: a lane owns, per row tile, 8 consecutive channels of a tile pair (16-byte stores) and 4 of an odd last tile
+  const int fl = p.flags;
+  const int wb = n0 + wc * (TN * 16);
+  const float* bw = bias_s + wc * (TN * 16);
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {                   // 64-row blocks (the granule of the GroupNorm partials)
+    float s1[TN][4], s2[TN][4];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      const int a = blk * 4 + a4;
+      const int m = m0 + wr * 128 + a * 16 + fr;
+      bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
+      const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
+      auto four = [&](const f32x4& v, int col, unsigned r0, unsigned r1, float* t1, float* t2) {
+        const float4 b = *(const float4*)(bw + col);
+        float v0 = v[0] * p.alpha + b.x, v1 = v[1] * p.alpha + b.y, v2 = v[2] * p.alpha + b.z, v3 = v[3] * p.alpha + b.w;
+        if (fl & CF_RES) {
+          v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
+          v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
+        }
+        if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (fl & CF_STATS) {
+          t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
+          t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
+          t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
+        }
+        return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+      };
+#pragma unroll
+      for (int t = 0; t < TN / 2; ++t) {
+        const int col = t * 32 + fq * 8;                // column of the pair's first value inside the wave's span
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (fl & CF_RES) rv = *(const uint4*)(rp + wb + col);
+        const uint2 lo = four(acc[a][2 * t], col, rv.x, rv.y, s1[2 * t], s2[2 * t]);
+        const uint2 hi = four(acc[a][2 * t + 1], col + 4, rv.z, rv.w, s1[2 * t + 1], s2[2 * t + 1]);
+        *(uint4*)(yp + wb + col) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      if constexpr (TN & 1) {
+        const int col = (TN - 1) * 16 + fq * 4;
+        uint2 rv = make_uint2(0, 0);
+        if (fl & CF_RES) rv = *(const uint2*)(rp + wb + col);
+        *(uint2*)(yp + wb + col) = four(acc[a][TN - 1], col, rv.x, rv.y, s1[TN - 1], s2[TN - 1]);
+      }
+    }
+    if (fl & CF_STATS) {
+      // per-(64-row block, channel) (mean, M2) of the stored values for the GroupNorm that consumes this tensor (conv_gemm2.hip emit_stats)
+      const int m0w = m0 + wr * 128 + blk * 64;
+      float* dst0 = p.stats + ((size_t)(m0w >> 6) * p.stats_ld) * 2;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sa = hrow16_sum(s1[jn][r]), sq = hrow16_sum(s2[jn][r]);
+          const float mean = sa * (1.f / 64.f);
+          o[2 * r] = mean; o[2 * r + 1] = fmaxf(sq - sa * mean, 0.f);
+        }
+        const int col = jn < TNP ? (jn >> 1) * 32 + fq * 8 + (jn & 1) * 4 : jn * 16 + fq * 4;
+        if (fr == 0) {
+          float* dst = dst0 + (size_t)(wb + col) * 2;                  // p.stats is already offset to this op's first channel
+          *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+    }
+  }
+}
+
+template <int TN>
+hipError_t run_halo(const ConvGemmParams& p, int lw, int halo_px, hipStream_t stream) {
+  constexpr int BN = 4 * TN * 16;
+  const int lds = 2 * BN * 128 + ((halo_px + 7) & ~7) * 128 + BN * 4 + 64;
+  static int attr = 0;
+  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
+  const int tiles = (p.M / 256) * (p.N / BN);
+  hipLaunchKernelGGL((conv_halo_kernel<TN>), dim3(tiles), dim3(512), lds, stream, p, lw, halo_px);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// 0 = not eligible, else TN (5: 256 x 320 tiles, 4: 256 x 256).  The host reads the tap table once per weight tensor elsewhere: here the
+// caller guarantees a 3x3 / pad 1 table (ntaps == 9 with offsets in {-1, 0, 1}^2), which every packer emits for KH = KW = 3, pad = 1.
+int conv_halo_config(const ConvGemmParams& p) {
+  static const int on = getenv("DD_CONV_HALO") ? atoi(getenv("DD_CONV_HALO")) : 1;
+  if (!on || p.force_small) return 0;
+  if (p.ntaps != 9 || p.stride != 1 || p.shift || p.parity || p.H != p.Ho || p.W != p.Wo || (p.cin & 63) || p.K != 9 * p.cin) return 0;
+  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS)) || p.bias_sel) return 0;
+  if (p.W < 16 || p.W > 128 || (p.W & (p.W - 1)) || ((p.H * p.W) & 255) || (p.M & 255) || p.M != p.B * p.H * p.W) return 0;
+  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
+  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;
+  if (p.ksplit > 1) return 0;
+  int tn = 0;
+  if (p.N % 320 == 0) tn = 5; else if (p.N % 256 == 0) tn = 4;
+  if (!tn) return 0;
+  const int tiles = (p.M / 256) * (p.N / (64 * tn));
+  if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
+  const int R = 256 / p.W, halo_px = (R + 2) * (p.W + 2);
+  if (2 * 64 * tn * 128 + ((halo_px + 7) & ~7) * 128 + 64 * tn * 4 + 64 > 163840) return 0;
+  return tn;
+}
+
+hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
+  int lw = 0;
+  while ((1 << lw) < p.W) ++lw;
+  const int R = 256 / p.W, halo_px = (R + 2) * (p.W + 2);
+  return tn == 5 ? run_halo<5>(p, lw, halo_px, stream) : run_halo<4>(p, lw, halo_px, stream);
+}

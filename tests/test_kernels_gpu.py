@@ -64,6 +64,12 @@ CONV_CASES = [
     ("big8_256x160_100steps", 4, 768, 160, 32, 32, 3, 1, 1, 0),
     ("big4_128x160_pointwise", 4, 1280, 320, 32, 32, 1, 1, 0, 0),
     ("big4_128x128_ragged", 3, 128, 384, 20, 21, 3, 1, 1, 0),
+    # 3x3 / stride 1 shapes with >= 192 tiles of 256 pixels, W a power of two, Cin % 64 == 0, N % 320 == 0 or % 256 == 0: the halo-resident
+    # ping-pong kernel (conv_halo.hip), forward and -- where Cin qualifies as N -- input-gradient; image widths 16 / 32 / 64 / 128
+    ("halo_320_32x32", 48, 320, 320, 32, 32, 3, 1, 1, 0),
+    ("halo_256_64x64", 12, 64, 256, 64, 64, 3, 1, 1, 0),
+    ("halo_640_16x16", 192, 128, 640, 16, 16, 3, 1, 1, 0),
+    ("halo_256_128x128", 3, 256, 256, 128, 128, 3, 1, 1, 0),
 ]
 
 
@@ -539,6 +545,8 @@ STATS_CASES = [
     ("fe_1x1_res", 2, 320, 640, 64, 64, 1, True),
     ("generic_256x160_deepK", 2, 960, 320, 128, 128, 3, False),
     ("two_wg_128x128", 1, 128, 128, 256, 256, 3, True),
+    ("halo_320_res", 48, 128, 320, 32, 32, 3, True),          # conv_halo.hip: 256 x 320 tiles, residual + partials
+    ("halo_256", 12, 64, 256, 64, 64, 3, False),               # 256 x 256 tiles
 ]
 
 

@@ -31,6 +31,9 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+__device__ int g_mode;
+__device__ unsigned* g_hwid;
+
 template <int TN>
 __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K) {
   constexpr int BM = 256, BN = 4 * TN * 16;
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int ktiles = K >> 6;
+  const int amode = g_mode;
 
   // DMA: wave w moves A pieces w, w + 8, ... and W pieces w, w + 8, ...; a lane's row inside its piece = lane >> 3, its 16-byte slot
   // is swizzled on the source side
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
   auto issue = [&](int kt, int which) {       // piece `which` of this wave for K-tile kt
     unsigned char* buf = smem + (kt & 1) * BUF;
     const unsigned soff = (unsigned)kt * 128u;
-    if (which < APC) dma16(A, buf + (wave + 8 * which) * 1024, aoff[which], soff);
+    // ablation (g_mode bit 4): the A operand is not re-loaded after K-tile 0 (what a halo slab would save for a 3x3 convolution: 8 of 9 taps)
+    if (which < APC) { if (!(amode & 16) || kt == 0) dma16(A, buf + (wave + 8 * which) * 1024, aoff[which], soff); }
     else dma16(W, buf + BM * 128 + (wave + 8 * (which - APC)) * 1024, woff[which - APC], soff);
   };
   constexpr int NP = APC + BPC;               // pieces per wave and K-tile, issued in strips 0..2
@@ -147,8 +152,7 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
 // LDS-DMA), one of each per SIMD.  Three 64-deep stages; one s_barrier per K-tile: behind barrier t every producer's pieces of tile t
 // have landed and every consumer has retired its reads of tile t - 1, whose stage the producers then refill with tile t + 2.
 // ------------------------------------------------------------------------------------------------------------------------------------
-__device__ int g_mode;
-__device__ unsigned* g_hwid;   // ablations: bit 0 = consumers skip the MFMAs, bit 1 = producers re-load K-tile 0 (cache-hot), bit 2 = consumers skip the LDS reads too
+// g_mode ablations of prodcons: bit 0 = consumers skip the MFMAs, bit 1 = producers re-load K-tile 0 (cache-hot), bit 2 = consumers skip the LDS reads, bit 3 = role placement
 __global__ __launch_bounds__(512, 1) void prodcons_kernel(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K) {
   const int mode = g_mode;
   constexpr int TN = 5, BM = 256, BN = 160, NS = 3;
