@@ -35,8 +35,14 @@ __device__ __forceinline__ float hrow16_sum(float v) {
   return v;
 }
 
+// Tile geometry (host: halo_geometry): a tile is th x tw OUTPUT pixels of one image (th * tw = 256, tw = min(Wo, 128) a power of two),
+// i.e. 256 / Wo whole image rows for Wo <= 128 and a 2 x 128 block for wider images; its halo is (th + 2) x (tw + 2) LOGICAL input
+// pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
+struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y; };
+
 template <int TN>
-__global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int lw, int halo_px) {
+__global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, HaloGeo geo) {
+  const int lw = geo.ltw, halo_px = geo.halo_px;
   constexpr int BM = 256, BN = 4 * TN * 16;
   constexpr int WB = BN * 128;                          // bytes of one weight stage
   constexpr unsigned OOB = 0xfffffff0u;
@@ -57,9 +63,12 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int
     const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-  const int HW = p.H * p.W;
-  const int img = m0 / HW, y0 = (m0 - img * HW) >> lw;  // first image row of the tile (tiles are whole image rows)
+  const int n0 = (tile % ntn) * BN;
+  const int mt = tile / ntn, tpi = geo.tiles_x * geo.tiles_y;
+  const int img = mt / tpi, tin = mt - img * tpi;
+  const int y0 = (tin / geo.tiles_x) * geo.th, x0 = (tin % geo.tiles_x) << lw;    // first output pixel of the tile inside its image
+  const int mimg = img * p.Ho * p.Wo;
+  auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };   // output row of tile pixel r
   const int chunks = p.cin >> 6, KT = chunks * 9;
 
   // ---- per-tap offsets: lane t holds tap t ((dy + 32) << 6 | (dx + 32)); read with readlane where needed
@@ -89,10 +98,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int
     for (int pc = wave; pc < npc; pc += 4) {
       const int hp = pc * 8 + prow;
       const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
-      const int iy = y0 - 1 + hy, ix = hx - 1;
-      const bool ok = hp < halo_px && iy >= 0 && iy < p.H && ix >= 0 && ix < Wd;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;       // logical input pixel (= output pixel coordinates: stride 1, pad 1)
+      const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
       const int j = (lane & 7) ^ (hx & 7);
-      const unsigned voff = ok ? ((unsigned)((img * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+      const unsigned voff = ok ? ((unsigned)((img * p.H + (iy >> p.shift)) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
       hdma16(p.x, halo + pc * 1024, voff, (unsigned)chunk * 128u);
     }
   };
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
       const int a = blk * 4 + a4;
-      const int m = m0 + wr * 128 + a * 16 + fr;
+      const int m = m_of(wr * 128 + a * 16 + fr);
       bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
       const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
       auto four = [&](const f32x4& v, int col, unsigned r0, unsigned r1, float* t1, float* t2) {
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int
     }
     if (fl & CF_STATS) {
       // per-(64-row block, channel) (mean, M2) of the stored values for the GroupNorm that consumes this tensor (conv_gemm2.hip emit_stats)
-      const int m0w = m0 + wr * 128 + blk * 64;
+      const int m0w = m_of(wr * 128 + blk * 64);           // 64 consecutive output rows (tw >= 64, or whole image rows)
       float* dst0 = p.stats + ((size_t)(m0w >> 6) * p.stats_ld) * 2;
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
@@ -244,14 +253,25 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, int
   }
 }
 
+bool halo_geometry(const ConvGemmParams& p, HaloGeo* g) {
+  const int Wo = p.Wo, Ho = p.Ho;
+  if (Wo < 16 || (Wo & (Wo - 1))) return false;
+  const int tw = Wo < 128 ? Wo : 128, th = 256 / tw;
+  if (Ho % th) return false;
+  int l = 0;
+  while ((1 << l) < tw) ++l;
+  g->ltw = l; g->th = th; g->halo_px = (th + 2) * (tw + 2); g->tiles_x = Wo / tw; g->tiles_y = Ho / th;
+  return true;
+}
+
 template <int TN>
-hipError_t run_halo(const ConvGemmParams& p, int lw, int halo_px, hipStream_t stream) {
+hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BN = 4 * TN * 16;
-  const int lds = 2 * BN * 128 + ((halo_px + 7) & ~7) * 128 + BN * 4 + 64;
+  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 64;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
   const int tiles = (p.M / 256) * (p.N / BN);
-  hipLaunchKernelGGL((conv_halo_kernel<TN>), dim3(tiles), dim3(512), lds, stream, p, lw, halo_px);
+  hipLaunchKernelGGL((conv_halo_kernel<TN>), dim3(tiles), dim3(512), lds, stream, p, g);
   return hipGetLastError();
 }
 
@@ -262,9 +282,11 @@ hipError_t run_halo(const ConvGemmParams& p, int lw, int halo_px, hipStream_t st
 int conv_halo_config(const ConvGemmParams& p) {
   static const int on = getenv("DD_CONV_HALO") ? atoi(getenv("DD_CONV_HALO")) : 1;
   if (!on || p.force_small) return 0;
-  if (p.ntaps != 9 || p.stride != 1 || p.shift || p.parity || p.H != p.Ho || p.W != p.Wo || (p.cin & 63) || p.K != 9 * p.cin) return 0;
+  if (p.ntaps != 9 || p.stride != 1 || p.shift > 1 || p.parity || (p.H << p.shift) != p.Ho || (p.W << p.shift) != p.Wo || (p.cin & 63) ||
+      p.K != 9 * p.cin) return 0;
   if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS)) || p.bias_sel) return 0;
-  if (p.W < 16 || p.W > 128 || (p.W & (p.W - 1)) || ((p.H * p.W) & 255) || (p.M & 255) || p.M != p.B * p.H * p.W) return 0;
+  HaloGeo g;
+  if (!halo_geometry(p, &g) || p.M != p.B * p.Ho * p.Wo) return 0;
   if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;
   if (p.ksplit > 1) return 0;
@@ -273,14 +295,12 @@ int conv_halo_config(const ConvGemmParams& p) {
   if (!tn) return 0;
   const int tiles = (p.M / 256) * (p.N / (64 * tn));
   if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
-  const int R = 256 / p.W, halo_px = (R + 2) * (p.W + 2);
-  if (2 * 64 * tn * 128 + ((halo_px + 7) & ~7) * 128 + 64 * tn * 4 + 64 > 163840) return 0;
+  if (2 * 64 * tn * 128 + ((g.halo_px + 7) & ~7) * 128 + 64 * tn * 4 + 64 > 163840) return 0;
   return tn;
 }
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
-  int lw = 0;
-  while ((1 << lw) < p.W) ++lw;
-  const int R = 256 / p.W, halo_px = (R + 2) * (p.W + 2);
-  return tn == 5 ? run_halo<5>(p, lw, halo_px, stream) : run_halo<4>(p, lw, halo_px, stream);
+  HaloGeo g;
+  if (!halo_geometry(p, &g)) return hipErrorInvalidValue;
+  return tn == 5 ? run_halo<5>(p, g, stream) : run_halo<4>(p, g, stream);
 }

@@ -70,6 +70,9 @@ CONV_CASES = [
     ("halo_256_64x64", 12, 64, 256, 64, 64, 3, 1, 1, 0),
     ("halo_640_16x16", 192, 128, 640, 16, 16, 3, 1, 1, 0),
     ("halo_256_128x128", 3, 256, 256, 128, 128, 3, 1, 1, 0),
+    ("halo_up2_320", 24, 128, 320, 32, 32, 3, 1, 1, 1),          # fused nearest-2x upsample: logical 64x64
+    ("halo_w256_2x128_tiles", 1, 64, 256, 256, 256, 3, 1, 1, 0),  # images wider than 128: 2 x 128-pixel tiles
+    ("halo_w512_up2", 1, 64, 256, 64, 256, 3, 1, 1, 1),           # logical 128 x 512
 ]
 
 
@@ -547,6 +550,7 @@ STATS_CASES = [
     ("two_wg_128x128", 1, 128, 128, 256, 256, 3, True),
     ("halo_320_res", 48, 128, 320, 32, 32, 3, True),          # conv_halo.hip: 256 x 320 tiles, residual + partials
     ("halo_256", 12, 64, 256, 64, 64, 3, False),               # 256 x 256 tiles
+    ("halo_w256_res", 1, 64, 256, 256, 256, 3, True),          # 2 x 128-pixel tiles: partial blocks of 64 rows inside a tile row
 ]
 
 
