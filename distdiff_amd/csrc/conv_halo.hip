@@ -40,10 +40,13 @@ __device__ __forceinline__ float hrow16_sum(float v) {
 // pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
 struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y; };
 
-template <int TN>
+// WN = 4: 256 x (64 TN) tiles, waves 2 (M) x 4 (N); WN = 2: 512 x (32 TN) tiles, waves 4 (M) x 2 (N) -- the narrow outputs of the decoder's
+// last level (N = 128).  Either way a wave owns 128 rows x TN * 16 columns and waves w, w + 4 (one SIMD) sit in different row groups.
+template <int TN, int WN>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, HaloGeo geo) {
   const int lw = geo.ltw, halo_px = geo.halo_px;
-  constexpr int BM = 256, BN = 4 * TN * 16;
+  constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
+  constexpr int NWP = BN / 64;                          // weight pieces (8 rows x 128 B) per wave and K-step
   constexpr int WB = BN * 128;                          // bytes of one weight stage
   constexpr unsigned OOB = 0xfffffff0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WN, wc = wave % WN;
+  const int grp = wave >> 2;                            // SIMD partners w, w + 4 are in different groups: group 1 runs one barrier behind
   const int fr = lane & 15, fq = lane >> 4;
   const int Wd = 1 << lw, W2 = Wd + 2;
 
@@ -80,9 +84,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   // consecutive channels (16-byte epilogue stores), exactly as in conv_gemm2.hip.
   const int prow = lane >> 3, jw = (lane & 7) ^ prow;
   constexpr int TNP = TN & ~1;
-  unsigned woff[TN];
+  unsigned woff[NWP];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
+  for (int i = 0; i < NWP; ++i) {
     const int R = (wave + 8 * i) * 8 + prow;
     const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
     const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   };
   // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
   const float inv_w2 = 1.f / (float)W2;
+  const bf16_t* ximg = p.x + (size_t)img * p.H * p.W * p.x_ld;     // per-image base: 32-bit byte offsets only span one image
   auto issue_halo = [&](int chunk) {
     const int npc = (halo_px + 7) >> 3;
     for (int pc = wave; pc < npc; pc += 4) {
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;       // logical input pixel (= output pixel coordinates: stride 1, pad 1)
       const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
       const int j = (lane & 7) ^ (hx & 7);
-      const unsigned voff = ok ? ((unsigned)((img * p.H + (iy >> p.shift)) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
-      hdma16(p.x, halo + pc * 1024, voff, (unsigned)chunk * 128u);
+      const unsigned voff = ok ? ((unsigned)((iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+      hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
     }
   };
 
@@ -113,19 +118,19 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue
-  if (wr == 0) issue_halo(0);
+  if (grp == 0) issue_halo(0);
 #pragma unroll
-  for (int i = 0; i < TN; ++i) issue_w(0, i);
+  for (int i = 0; i < NWP; ++i) issue_w(0, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                      // also publishes bias_s
-  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
+  if (grp == 1) __builtin_amdgcn_s_barrier();           // the second group runs one barrier behind
 
   bf16x8 wf[TN][2], xf[2][2];
   int kt = 0;
   for (int c = 0; c < chunks; ++c) {
     if (c > 0) {
       // every read of the previous chunk's halo has retired (both halves waited lgkmcnt(0) in front of their last X barrier)
-      if (wr == 0) { issue_halo(c); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      if (grp == 0) { issue_halo(c); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __builtin_amdgcn_s_barrier();
     }
     for (int t = 0; t < 9; ++t, ++kt) {
@@ -155,10 +160,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
           for (int ks = 0; ks < 2; ++ks) xf[i][ks] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xs) << 4));
         }
         if (s < 3 && more) {
-          constexpr int PP = (TN + 2) / 3;
+          constexpr int PP = (NWP + 2) / 3;
 #pragma unroll
           for (int q = 0; q < PP; ++q)
-            if (s * PP + q < TN) issue_w(kt + 1, s * PP + q);
+            if (s * PP + q < NWP) issue_w(kt + 1, s * PP + q);
         }
         // last strip: this wave's weight pieces of K-step kt + 1 have landed and its LDS reads of this stage (and, on tap 8, of the
         // halo) have retired BEFORE the barrier behind which the other half reads the new stage / the halo is refilled
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
       }
     }
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();            // balance the barrier count of the two halves
+  if (grp == 0) __builtin_amdgcn_s_barrier();           // balance the barrier count of the two groups
 
   // ---- epilogue: a lane owns, per row tile, 8 consecutive channels of a tile pair (16-byte stores) and 4 of an odd last tile
   const int fl = p.flags;
@@ -253,10 +258,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
 }
 
-bool halo_geometry(const ConvGemmParams& p, HaloGeo* g) {
+bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   const int Wo = p.Wo, Ho = p.Ho;
   if (Wo < 16 || (Wo & (Wo - 1))) return false;
-  const int tw = Wo < 128 ? Wo : 128, th = 256 / tw;
+  const int tw = Wo < 128 ? Wo : 128, th = bm / tw;
   if (Ho % th) return false;
   int l = 0;
   while ((1 << l) < tw) ++l;
@@ -264,20 +269,20 @@ bool halo_geometry(const ConvGemmParams& p, HaloGeo* g) {
   return true;
 }
 
-template <int TN>
+template <int TN, int WN>
 hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
-  constexpr int BN = 4 * TN * 16;
+  constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
   const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 64;
   static int attr = 0;
-  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
-  const int tiles = (p.M / 256) * (p.N / BN);
-  hipLaunchKernelGGL((conv_halo_kernel<TN>), dim3(tiles), dim3(512), lds, stream, p, g);
+  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
+  const int tiles = (p.M / BM) * (p.N / BN);
+  hipLaunchKernelGGL((conv_halo_kernel<TN, WN>), dim3(tiles), dim3(512), lds, stream, p, g);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// 0 = not eligible, else TN (5: 256 x 320 tiles, 4: 256 x 256).  The host reads the tap table once per weight tensor elsewhere: here the
+// 0 = not eligible, else the tile form: 5 = 256 x 320, 4 = 256 x 256, 2 = 512 x 128 (N = 128).  The host reads the tap table once per weight tensor elsewhere: here the
 // caller guarantees a 3x3 / pad 1 table (ntaps == 9 with offsets in {-1, 0, 1}^2), which every packer emits for KH = KW = 3, pad = 1.
 int conv_halo_config(const ConvGemmParams& p) {
   static const int on = getenv("DD_CONV_HALO") ? atoi(getenv("DD_CONV_HALO")) : 1;
@@ -285,22 +290,23 @@ int conv_halo_config(const ConvGemmParams& p) {
   if (p.ntaps != 9 || p.stride != 1 || p.shift > 1 || p.parity || (p.H << p.shift) != p.Ho || (p.W << p.shift) != p.Wo || (p.cin & 63) ||
       p.K != 9 * p.cin) return 0;
   if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS)) || p.bias_sel) return 0;
-  HaloGeo g;
-  if (!halo_geometry(p, &g) || p.M != p.B * p.Ho * p.Wo) return 0;
-  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
-  if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;
-  if (p.ksplit > 1) return 0;
   int tn = 0;
-  if (p.N % 320 == 0) tn = 5; else if (p.N % 256 == 0) tn = 4;
+  if (p.N % 320 == 0) tn = 5; else if (p.N % 256 == 0) tn = 4; else if (p.N == 128) tn = 2;
   if (!tn) return 0;
-  const int tiles = (p.M / 256) * (p.N / (64 * tn));
+  const int bm = tn == 2 ? 512 : 256, bn = tn == 2 ? 128 : 64 * tn;
+  HaloGeo g;
+  if (!halo_geometry(p, bm, &g) || p.M != p.B * p.Ho * p.Wo) return 0;
+  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
+  if ((size_t)p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;         // byte offsets are per image
+  if (p.ksplit > 1) return 0;
+  const int tiles = (p.M / bm) * (p.N / bn);
   if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
-  if (2 * 64 * tn * 128 + ((g.halo_px + 7) & ~7) * 128 + 64 * tn * 4 + 64 > 163840) return 0;
+  if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 64 > 163840) return 0;
   return tn;
 }
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
   HaloGeo g;
-  if (!halo_geometry(p, &g)) return hipErrorInvalidValue;
-  return tn == 5 ? run_halo<5>(p, g, stream) : run_halo<4>(p, g, stream);
+  if (!halo_geometry(p, tn == 2 ? 512 : 256, &g)) return hipErrorInvalidValue;
+  return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

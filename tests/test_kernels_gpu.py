@@ -73,6 +73,7 @@ CONV_CASES = [
     ("halo_up2_320", 24, 128, 320, 32, 32, 3, 1, 1, 1),          # fused nearest-2x upsample: logical 64x64
     ("halo_w256_2x128_tiles", 1, 64, 256, 256, 256, 3, 1, 1, 0),  # images wider than 128: 2 x 128-pixel tiles
     ("halo_w512_up2", 1, 64, 256, 64, 256, 3, 1, 1, 1),           # logical 128 x 512
+    ("halo_n128_512x128_tiles", 1, 128, 128, 256, 512, 3, 1, 1, 0),  # N = 128: 512-row tiles (4 x 128 pixels), waves 4 x 2
 ]
 
 
@@ -551,6 +552,7 @@ STATS_CASES = [
     ("halo_320_res", 48, 128, 320, 32, 32, 3, True),          # conv_halo.hip: 256 x 320 tiles, residual + partials
     ("halo_256", 12, 64, 256, 64, 64, 3, False),               # 256 x 256 tiles
     ("halo_w256_res", 1, 64, 256, 256, 256, 3, True),          # 2 x 128-pixel tiles: partial blocks of 64 rows inside a tile row
+    ("halo_n128_res", 1, 64, 128, 512, 512, 3, True),          # 512 x 128 tiles
 ]
 
 
