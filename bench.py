@@ -114,23 +114,35 @@ def unet_flops_per_sample(cfg):
 def recorded_traffic(B, config):
     """HBM bytes per conv launch from the committed PMC passes (profiles/, tools/pmc_summary.py).
 
-    PMC collection needs rocprofv3 around the whole process, so it cannot run inside the timed region; the
-    number is only attached when the committed passes were taken on this exact workload (same batch)."""
+    PMC collection needs rocprofv3 around the whole process, so it cannot run inside the timed region; the number comes from the
+    newest committed passes of this workload: of the same batch when they exist, else of another batch scaled by the batch ratio
+    (every conv launch's bytes are proportional to the batch; round 3: rocprofv3's PMC pass segfaults inside the tool at 32 images /
+    239 GB resident, so the passes were taken at 16 images)."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((p for p in (os.path.join(root, "r%02d_b%d_pmc_traffic.json" % (r, B)) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)) if os.path.exists(p)),
-                None)
+    path, scale = None, 1.0
+    for r in (9, 8, 7, 6, 5, 4, 3, 2, 1):
+        for b in (B, 32, 16, 8):
+            cand = os.path.join(root, "r%02d_b%d_pmc_traffic.json" % (r, b))
+            if os.path.exists(cand):
+                path, scale = cand, float(B) / b
+                break
+        if path:
+            break
     if config != "sd15" or path is None:
         return {}
     with open(path) as f:
         t = json.load(f)
     byts = launches = 0.0
-    for fam in ("conv_gemm_big_kernel", "conv_gemm_kernel", "splitk"):
+    for fam in ("conv_gemm_big_kernel", "conv_halo_kernel", "conv_gemm_kernel", "splitk"):
         if fam in t:
             byts += t[fam]["hbm_fetch_bytes_corrected"] + t[fam]["hbm_write_bytes"]
             if fam != "splitk":
                 launches += t[fam]["launches"]
-    return {"traffic": byts / max(launches, 1.0), "traffic_unit": "HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE)",
-            "traffic_source": "profiles/" + os.path.basename(path) + " (separate rocprofv3 --pmc passes of this command)"}
+    src = "profiles/" + os.path.basename(path) + " (separate rocprofv3 --pmc passes of this command)"
+    if scale != 1.0:
+        src += ", scaled x%.2f to %d images per step" % (scale, B)
+    return {"traffic": scale * byts / max(launches, 1.0), "traffic_unit": "HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": src}
 
 
 def main():
@@ -284,7 +296,7 @@ def main():
         if prof is not None:
             cv = prof["conv_gemm"]
             ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": cv["ops"], "avg_launch_ms": cv["ms"] / max(cv["ops"], 1),
                                "algorithmic_flops_per_launch": cv["flops"] / max(cv["ops"], 1),
