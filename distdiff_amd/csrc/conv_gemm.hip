@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvGemmParams p) {
 int conv_gemm_big_config(int M, int N, int K, int flags);
 int conv_halo_config(const ConvGemmParams& p);           // conv_halo.hip: 0, or the tile form of the halo-resident 3x3 kernel
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream);
+int gemm_pp_config(const ConvGemmParams& p);             // conv_halo.hip: pointwise ping-pong GEMM (narrow N)
+hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream);
 void conv_gemm_big_tile(int cfg, int* bm, int* bn);
 hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream);
 
@@ -332,7 +334,7 @@ bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes) {
   if ((p.K & 63) || p.M <= 0 || p.N <= 0 || (p.M & 63) || (p.N & 7) || (p.y_ld & 7)) return false;
   if (p.flags & (CF_GEGLU | CF_OUT_F32 | CF_MASK | CF_RES_F32)) return false;
   if ((p.flags & CF_RES) && (p.res_ld & 7)) return false;
-  { ConvGemmParams q = p; q.flags |= CF_STATS; if (conv_halo_config(q)) return true; }
+  { ConvGemmParams q = p; q.flags |= CF_STATS; if (conv_halo_config(q) || gemm_pp_config(q)) return true; }
   int cfg, split;
   select_config(p, partial_cap_bytes, &cfg, &split);
   if (!cfg || split != 1) return false;
@@ -348,6 +350,7 @@ bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int
   // the batched epilogue of the two-workgroup pointwise forms only (fast staging: Cin % 64 == 0, one tap, no upsample)
   if ((p.cin & 63) || p.shift || p.ntaps != 1 || p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return false;
+  { ConvGemmParams q = p; q.flags |= CF_ROWSTATS; if (gemm_pp_config(q)) { if (spans) *spans = p.N / 80; return true; } }
   int cfg, split;
   select_config(p, partial_cap_bytes, &cfg, &split);
   const int span = cfg ? conv_gemm_big_rowstat_span(cfg) : 0;
@@ -368,6 +371,7 @@ hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStrea
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if ((p.flags & CF_STATS) && (!p.stats || !conv_gemm_can_emit_stats(p, partial_cap_bytes))) return hipErrorInvalidValue;
   if (const int tn = conv_halo_config(p)) return launch_conv_halo(p, tn, stream);       // deep 3x3 / stride 1: halo-resident input tile
+  if (const int tn = gemm_pp_config(p)) return launch_gemm_pp(p, tn, stream);           // narrow pointwise layers: ping-pong GEMM
   int cfg, split;
   select_config(p, partial_cap_bytes, &cfg, &split);
   p.ksplit = split;

@@ -35,6 +35,103 @@ __device__ __forceinline__ float hrow16_sum(float v) {
   return v;
 }
 
+// Shared epilogue of the ping-pong kernels: a lane owns, per 16-row tile a, 8 consecutive channels of a tile pair (16-byte loads /
+// stores) and 4 of an odd last tile.  bias / residual / ReLU / CF_STATS (GroupNorm partials per 64-row block) as in conv_gemm2.hip, plus
+// CF_LNFOLD (out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n]: the LayerNorm in front of this linear is folded into its weights) and
+// CF_ROWSTATS ((sum, sum^2) of every output row over this wave's TN * 16 columns, for the LayerNorm that consumes the tensor).
+template <int TN, class MOf>
+__device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc)[8][TN], MOf m_of, int wr, int wc, int n0,
+                                            const float* bias_s, const float* c1_s, int span, int fr, int fq) {
+  constexpr int TNP = TN & ~1;
+  const int fl = p.flags;
+  const int wb = n0 + wc * (TN * 16);
+  const float* bw = bias_s + wc * (TN * 16);
+  const float* cw = c1_s + wc * (TN * 16);
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {                   // 64-row blocks (the granule of the GroupNorm partials)
+    float s1[TN][4], s2[TN][4];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      const int a = blk * 4 + a4;
+      const int m = m_of(wr * 128 + a * 16 + fr);
+      bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
+      const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
+      float rs = p.alpha, nm = 0.f;                      // CF_LNFOLD: rstd and -rstd * mean of this lane's row
+      if (fl & CF_LNFOLD) { const float2 st = *(const float2*)(p.ln_stats + (size_t)m * 2); rs = st.y * p.alpha; nm = -st.y * st.x; }
+      float r1 = 0.f, r2 = 0.f;                          // CF_ROWSTATS
+      auto four = [&](const f32x4& v, int col, unsigned q0, unsigned q1, float* t1, float* t2) {
+        float4 b = *(const float4*)(bw + col);
+        if (fl & CF_LNFOLD) {
+          const float4 c = *(const float4*)(cw + col);
+          b.x = __builtin_fmaf(nm, c.x, b.x); b.y = __builtin_fmaf(nm, c.y, b.y); b.z = __builtin_fmaf(nm, c.z, b.z); b.w = __builtin_fmaf(nm, c.w, b.w);
+        }
+        float v0 = __builtin_fmaf(v[0], rs, b.x), v1 = __builtin_fmaf(v[1], rs, b.y), v2 = __builtin_fmaf(v[2], rs, b.z), v3 = __builtin_fmaf(v[3], rs, b.w);
+        if (fl & CF_RES) {
+          v0 += __uint_as_float(q0 << 16); v1 += __uint_as_float(q0 & 0xffff0000u);
+          v2 += __uint_as_float(q1 << 16); v3 += __uint_as_float(q1 & 0xffff0000u);
+        }
+        if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (fl & CF_STATS) {
+          t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
+          t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
+          t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
+        }
+        if (fl & CF_ROWSTATS) {
+          r1 += (v0 + v1) + (v2 + v3);
+          r2 = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, r2))));
+        }
+        return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+      };
+#pragma unroll
+      for (int t = 0; t < TN / 2; ++t) {
+        const int col = t * 32 + fq * 8;                // column of the pair's first value inside the wave's span
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (fl & CF_RES) rv = *(const uint4*)(rp + wb + col);
+        const uint2 lo = four(acc[a][2 * t], col, rv.x, rv.y, s1[2 * t], s2[2 * t]);
+        const uint2 hi = four(acc[a][2 * t + 1], col + 4, rv.z, rv.w, s1[2 * t + 1], s2[2 * t + 1]);
+        *(uint4*)(yp + wb + col) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      if constexpr (TN & 1) {
+        const int col = (TN - 1) * 16 + fq * 4;
+        uint2 rv = make_uint2(0, 0);
+        if (fl & CF_RES) rv = *(const uint2*)(rp + wb + col);
+        *(uint2*)(yp + wb + col) = four(acc[a][TN - 1], col, rv.x, rv.y, s1[TN - 1], s2[TN - 1]);
+      }
+      if (fl & CF_ROWSTATS) {
+        // the row's TN * 16 columns of this wave sit in lanes fr, fr + 16, fr + 32, fr + 48
+        r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
+        r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
+        if (fq == 0) *(float2*)(p.rowpart + ((size_t)m * p.rowpart_ld + span) * 2) = make_float2(r1, r2);
+      }
+    }
+    if (fl & CF_STATS) {
+      // per-(64-row block, channel) (mean, M2) of the stored values for the GroupNorm that consumes this tensor (conv_gemm2.hip emit_stats)
+      const int m0w = m_of(wr * 128 + blk * 64);           // 64 consecutive output rows (tw >= 64, or whole image rows)
+      float* dst0 = p.stats + ((size_t)(m0w >> 6) * p.stats_ld) * 2;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sa = hrow16_sum(s1[jn][r]), sq = hrow16_sum(s2[jn][r]);
+          const float mean = sa * (1.f / 64.f);
+          o[2 * r] = mean; o[2 * r + 1] = fmaxf(sq - sa * mean, 0.f);
+        }
+        const int col = jn < TNP ? (jn >> 1) * 32 + fq * 8 + (jn & 1) * 4 : jn * 16 + fq * 4;
+        if (fr == 0) {
+          float* dst = dst0 + (size_t)(wb + col) * 2;                  // p.stats is already offset to this op's first channel
+          *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+    }
+  }
+}
+
 // Tile geometry (host: halo_geometry): a tile is th x tw OUTPUT pixels of one image (th * tw = 256, tw = min(Wo, 128) a power of two),
 // i.e. 256 / Wo whole image rows for Wo <= 128 and a 2 x 128 block for wider images; its halo is (th + 2) x (tw + 2) LOGICAL input
 // pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
@@ -186,76 +283,116 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();           // balance the barrier count of the two groups
 
-  // ---- epilogue: a lane owns, per row tile, 8 consecutive channels of a tile pair (16-byte stores) and 4 of an odd last tile
-  const int fl = p.flags;
-  const int wb = n0 + wc * (TN * 16);
-  const float* bw = bias_s + wc * (TN * 16);
+  pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s, 0, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same ping-pong K loop for pointwise (1x1 / linear) layers with narrow outputs (N <= 1280: to_out, to_q, proj_in / proj_out,
+// ff.net.2 of the transformer blocks): 256 x 320 tiles, both operands streamed through two 64-deep stages (A 32 KB + W 40 KB per
+// K-step: 6.9 B per kFLOP against 13.8 for the 128 x 160 two-workgroup form), every A row read once.  Same-device micro-benchmark
+// (tools/micro/pingpong_gemm.hip): 320 x 320 at M = 262144 103 us vs 140 us, 640 x 640 62 vs 96, 1280 x 1280 50 vs 72, ff.net.2
+// 320 x 1280 232 vs 325 us.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
+  constexpr int BM = 256, BN = 4 * TN * 16;
+  constexpr int BUF = (BM + BN) * 128;
+  constexpr int NP = 4 + TN;                           // pieces per wave and K-step: 4 of A, TN of W
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const bias_s = (float*)(smem + 2 * BUF);
+  float* const c1_s = bias_s + BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
+  int tile;
+  {
+    const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int KT = p.K >> 6;
+  if (tid < BN) {
+    bias_s[tid] = (p.flags & CF_BIAS) ? p.bias[n0 + tid] : 0.f;
+    c1_s[tid] = (p.flags & CF_LNFOLD) ? p.ln_c1[n0 + tid] : 0.f;
+  }
+  const int prow = lane >> 3, j = (lane & 7) ^ prow;
+  constexpr int TNP = TN & ~1;
+  const bf16_t* xt = p.x + (size_t)m0 * p.x_ld;          // per-tile base: 32-bit byte offsets only span 256 rows
+  unsigned aoff[4], woff[TN];
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {                   // 64-row blocks (the granule of the GroupNorm partials)
-    float s1[TN][4], s2[TN][4];
+  for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)((wave + 8 * i) * 8 + prow) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
+  for (int i = 0; i < TN; ++i) {
+    const int R = (wave + 8 * i) * 8 + prow;
+    const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
+    const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
+    woff[i] = ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(j * 8)) * 2u;
+  }
+  auto issue = [&](int kt, int which) {
+    unsigned char* buf = smem + (kt & 1) * BUF;
+    const unsigned soff = (unsigned)kt * 128u;
+    if (which < 4) hdma16(xt, buf + (wave + 8 * which) * 1024, aoff[which], soff);
+    else hdma16(p.w, buf + BM * 128 + (wave + 8 * (which - 4)) * 1024, woff[which - 4], soff);
+  };
+  f32x4 acc[8][TN];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
+  for (int a = 0; a < 8; ++a)
 #pragma unroll
-    for (int a4 = 0; a4 < 4; ++a4) {
-      const int a = blk * 4 + a4;
-      const int m = m_of(wr * 128 + a * 16 + fr);
-      bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
-      const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
-      auto four = [&](const f32x4& v, int col, unsigned r0, unsigned r1, float* t1, float* t2) {
-        const float4 b = *(const float4*)(bw + col);
-        float v0 = v[0] * p.alpha + b.x, v1 = v[1] * p.alpha + b.y, v2 = v[2] * p.alpha + b.z, v3 = v[3] * p.alpha + b.w;
-        if (fl & CF_RES) {
-          v0 += __uint_as_float(r0 << 16); v1 += __uint_as_float(r0 & 0xffff0000u);
-          v2 += __uint_as_float(r1 << 16); v3 += __uint_as_float(r1 & 0xffff0000u);
-        }
-        if (fl & CF_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        if (fl & CF_STATS) {
-          t1[0] += v0; t1[1] += v1; t1[2] += v2; t1[3] += v3;
-          t2[0] = __builtin_fmaf(v0, v0, t2[0]); t2[1] = __builtin_fmaf(v1, v1, t2[1]);
-          t2[2] = __builtin_fmaf(v2, v2, t2[2]); t2[3] = __builtin_fmaf(v3, v3, t2[3]);
-        }
-        return make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-      };
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < TN / 2; ++t) {
-        const int col = t * 32 + fq * 8;                // column of the pair's first value inside the wave's span
-        uint4 rv = make_uint4(0, 0, 0, 0);
-        if (fl & CF_RES) rv = *(const uint4*)(rp + wb + col);
-        const uint2 lo = four(acc[a][2 * t], col, rv.x, rv.y, s1[2 * t], s2[2 * t]);
-        const uint2 hi = four(acc[a][2 * t + 1], col + 4, rv.z, rv.w, s1[2 * t + 1], s2[2 * t + 1]);
-        *(uint4*)(yp + wb + col) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  for (int q = 0; q < NP; ++q) issue(0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
+  bf16x8 wf[TN][2], xf[2][2];
+  for (int kt = 0; kt < KT; ++kt) {
+    const unsigned char* Ab = smem + (kt & 1) * BUF;
+    const unsigned char* Bb = Ab + BM * 128;
+    const bool more = kt + 1 < KT;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s == 0) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int row = wc * (TN * 16) + jn * 16 + fr;
+            wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+          }
       }
-      if constexpr (TN & 1) {
-        const int col = (TN - 1) * 16 + fq * 4;
-        uint2 rv = make_uint2(0, 0);
-        if (fl & CF_RES) rv = *(const uint2*)(rp + wb + col);
-        *(uint2*)(yp + wb + col) = four(acc[a][TN - 1], col, rv.x, rv.y, s1[TN - 1], s2[TN - 1]);
-      }
-    }
-    if (fl & CF_STATS) {
-      // per-(64-row block, channel) (mean, M2) of the stored values for the GroupNorm that consumes this tensor (conv_gemm2.hip emit_stats)
-      const int m0w = m_of(wr * 128 + blk * 64);           // 64 consecutive output rows (tw >= 64, or whole image rows)
-      float* dst0 = p.stats + ((size_t)(m0w >> 6) * p.stats_ld) * 2;
 #pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        float o[8];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sa = hrow16_sum(s1[jn][r]), sq = hrow16_sum(s2[jn][r]);
-          const float mean = sa * (1.f / 64.f);
-          o[2 * r] = mean; o[2 * r + 1] = fmaxf(sq - sa * mean, 0.f);
+        for (int ks = 0; ks < 2; ++ks) {
+          const int row = wr * 128 + s * 32 + i * 16 + fr;
+          xf[i][ks] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
         }
-        const int col = jn < TNP ? (jn >> 1) * 32 + fq * 8 + (jn & 1) * 4 : jn * 16 + fq * 4;
-        if (fr == 0) {
-          float* dst = dst0 + (size_t)(wb + col) * 2;                  // p.stats is already offset to this op's first channel
-          *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-          *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-        }
+      if (s < 3 && more) {
+        constexpr int PP = (NP + 2) / 3;
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+          if (s * PP + q < NP) issue(kt + 1, s * PP + q);
       }
+      if (s == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
     }
   }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  auto m_of = [&](int r) { return m0 + r; };
+  pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, c1_s, (n0 / BN) * 4 + wc, fr, fq);
 }
 
 bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
@@ -303,6 +440,28 @@ int conv_halo_config(const ConvGemmParams& p) {
   if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
   if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 64 > 163840) return 0;
   return tn;
+}
+
+// pointwise ping-pong GEMM: 0 = not eligible, else TN (5: 256 x 320 tiles)
+int gemm_pp_config(const ConvGemmParams& p) {
+  static const int on = getenv("DD_GEMM_PP") ? atoi(getenv("DD_GEMM_PP")) : 1;
+  if (!on || p.force_small) return 0;
+  if (p.ntaps != 1 || p.stride != 1 || p.shift || p.parity || p.H != p.Ho || p.W != p.Wo || (p.cin & 63) || p.K != p.cin) return 0;
+  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_ROWSTATS | CF_LNFOLD)) || p.bias_sel) return 0;
+  if (p.N % 320 || p.N > 1280 || (p.M & 255) || p.K < 256 || p.ksplit > 1) return 0;
+  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7)) return 0;
+  if ((size_t)256 * p.x_ld * 2 >= 0xF0000000ull) return 0;
+  if ((p.M / 256) * (p.N / 320) < 192) return 0;
+  return 5;
+}
+hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream) {
+  constexpr int BN = 320;
+  const int lds = 2 * (256 + BN) * 128 + 2 * BN * 4 + 64;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)gemm_pp_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  (void)tn;
+  hipLaunchKernelGGL((gemm_pp_kernel<5>), dim3((p.M / 256) * (p.N / BN)), dim3(512), lds, stream, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {

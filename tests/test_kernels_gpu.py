@@ -259,12 +259,13 @@ def test_layernorm(ops, Cc):
 
 
 @pytest.mark.parametrize("M,Cc,N,geglu", [(4096, 320, 960, False), (2048, 640, 640, False), (4096, 320, 2560, True), (300, 320, 320, False),
-                                            (1024, 1280, 3840, False)])
+                                            (1024, 1280, 3840, False), (49152, 320, 960, False), (49152, 640, 640, False)])
 def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
     """CF_LNFOLD: LayerNorm(x) W^T + b computed as rstd * (x (gamma o W)^T - mean * c1) + (b + W beta) from the RAW x and the row
     statistics -- the transformer blocks' LayerNorm -> QKV / to_q / GEGLU projections (diffusers BasicTransformerBlock).
     Checked against torch's layer_norm + linear on the same bf16 inputs (the folded form never rounds LayerNorm(x) to bf16, so it is
-    the more accurate of the two); M = 300 takes the small kernel's generic epilogue, the others the batched two-workgroup forms."""
+    the more accurate of the two); M = 300 takes the small kernel's generic epilogue, M = 49152 (>= 192 tiles of 256 rows, N <= 1280) the
+    ping-pong GEMM of conv_halo.hip, the others the batched two-workgroup forms."""
     g = torch.Generator().manual_seed(77)
     x = bf(torch.randn(M, Cc, generator=g) * 1.7 + torch.randn(M, 1, generator=g) * 0.8)      # row means of the size of the row std
     gamma, beta = 1.0 + 0.3 * torch.randn(Cc, generator=g), 0.2 * torch.randn(Cc, generator=g)
@@ -288,7 +289,7 @@ def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
     assert_close(y, ref, rtol=1.5e-2, atol=2e-2, what="ln-folded linear")
 
 
-@pytest.mark.parametrize("M,K,N", [(16384, 320, 320), (8192, 1280, 640), (3000, 640, 1280)])
+@pytest.mark.parametrize("M,K,N", [(16384, 320, 320), (8192, 1280, 640), (3000, 640, 1280), (49152, 320, 320), (49152, 1280, 640)])
 def test_linear_emits_layernorm_row_partials(ops, M, K, N):
     """CF_ROWSTATS: the to_out / ff.net.2 / proj_in GEMMs emit (sum, sum^2) of every output row per 80-column wave span; the LayerNorm
     that follows finalises (mean, rstd) from them instead of reading the tensor."""
