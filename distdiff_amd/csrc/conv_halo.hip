@@ -55,13 +55,34 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
 #pragma unroll
-    for (int a4 = 0; a4 < 4; ++a4) {
-      const int a = blk * 4 + a4;
-      const int m = m_of(wr * 128 + a * 16 + fr);
+    for (int hb = 0; hb < 2; ++hb) {
+    // the residual rows / LayerNorm statistics of two 16-row tiles are requested before their first use: one exposed memory latency per
+    // 32 rows instead of one per tile pair (the accumulators and the GroupNorm sums leave ~50 registers free here)
+    uint4 rvp[2][TN / 2];
+    uint2 rvo[2];
+    float2 lst[2];
+    int mrow[2];
+#pragma unroll
+    for (int a4 = 0; a4 < 2; ++a4) {
+      mrow[a4] = m_of(wr * 128 + (blk * 4 + hb * 2 + a4) * 16 + fr);
+      const bf16_t* rp = (const bf16_t*)p.res + (size_t)mrow[a4] * p.res_ld + wb;
+      if (fl & CF_RES) {
+#pragma unroll
+        for (int t = 0; t < TN / 2; ++t) rvp[a4][t] = *(const uint4*)(rp + t * 32 + fq * 8);
+        if constexpr (TN & 1) rvo[a4] = *(const uint2*)(rp + (TN - 1) * 16 + fq * 4);
+      } else {
+#pragma unroll
+        for (int t = 0; t < TN / 2; ++t) rvp[a4][t] = make_uint4(0, 0, 0, 0);
+        rvo[a4] = make_uint2(0, 0);
+      }
+      lst[a4] = (fl & CF_LNFOLD) ? *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2) : make_float2(0.f, 1.f);
+    }
+#pragma unroll
+    for (int a4 = 0; a4 < 2; ++a4) {
+      const int a = blk * 4 + hb * 2 + a4;
+      const int m = mrow[a4];
       bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
-      const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.res_ld;
-      float rs = p.alpha, nm = 0.f;                      // CF_LNFOLD: rstd and -rstd * mean of this lane's row
-      if (fl & CF_LNFOLD) { const float2 st = *(const float2*)(p.ln_stats + (size_t)m * 2); rs = st.y * p.alpha; nm = -st.y * st.x; }
+      const float rs = lst[a4].y * p.alpha, nm = -lst[a4].y * lst[a4].x;      // CF_LNFOLD: rstd and -rstd * mean of this lane's row (1, 0 otherwise)
       float r1 = 0.f, r2 = 0.f;                          // CF_ROWSTATS
       auto four = [&](const f32x4& v, int col, unsigned q0, unsigned q1, float* t1, float* t2) {
         float4 b = *(const float4*)(bw + col);
@@ -89,17 +110,14 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int t = 0; t < TN / 2; ++t) {
         const int col = t * 32 + fq * 8;                // column of the pair's first value inside the wave's span
-        uint4 rv = make_uint4(0, 0, 0, 0);
-        if (fl & CF_RES) rv = *(const uint4*)(rp + wb + col);
+        const uint4 rv = rvp[a4][t];
         const uint2 lo = four(acc[a][2 * t], col, rv.x, rv.y, s1[2 * t], s2[2 * t]);
         const uint2 hi = four(acc[a][2 * t + 1], col + 4, rv.z, rv.w, s1[2 * t + 1], s2[2 * t + 1]);
         *(uint4*)(yp + wb + col) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
       if constexpr (TN & 1) {
         const int col = (TN - 1) * 16 + fq * 4;
-        uint2 rv = make_uint2(0, 0);
-        if (fl & CF_RES) rv = *(const uint2*)(rp + wb + col);
-        *(uint2*)(yp + wb + col) = four(acc[a][TN - 1], col, rv.x, rv.y, s1[TN - 1], s2[TN - 1]);
+        *(uint2*)(yp + wb + col) = four(acc[a][TN - 1], col, rvo[a4].x, rvo[a4].y, s1[TN - 1], s2[TN - 1]);
       }
       if (fl & CF_ROWSTATS) {
         // the row's TN * 16 columns of this wave sit in lanes fr, fr + 16, fr + 32, fr + 48
@@ -107,6 +125,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
         r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
         if (fq == 0) *(float2*)(p.rowpart + ((size_t)m * p.rowpart_ld + span) * 2) = make_float2(r1, r2);
       }
+    }
     }
     if (fl & CF_STATS) {
       // per-(64-row block, channel) (mean, M2) of the stored values for the GroupNorm that consumes this tensor (conv_gemm2.hip emit_stats)
