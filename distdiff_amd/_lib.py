@@ -40,9 +40,9 @@ vp = C.c_void_p
 
 class ConvGemmParams(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("taptab", vp), ("y", vp), ("bias", vp), ("bias_sel", vp), ("res", vp),
-                ("mask", vp), ("raw", vp), ("partial", vp), ("stats", vp), ("ln_stats", vp), ("ln_c1", vp), ("rowpart", vp),
+                ("mask", vp), ("raw", vp), ("partial", vp), ("stats", vp), ("ln_stats", vp), ("ln_c1", vp), ("gn_coef", vp), ("rowpart", vp),
                 ("x_ld", C.c_int), ("y_ld", C.c_int), ("res_ld", C.c_int), ("mask_ld", C.c_int), ("raw_ld", C.c_int),
-                ("bias_stride", C.c_int), ("stats_ld", C.c_int), ("rowpart_ld", C.c_int),
+                ("bias_stride", C.c_int), ("stats_ld", C.c_int), ("rowpart_ld", C.c_int), ("gn_silu", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("stride", C.c_int),
                 ("shift", C.c_int), ("parity", C.c_int), ("cin", C.c_int), ("ntaps", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ksplit", C.c_int), ("flags", C.c_int),
@@ -51,7 +51,7 @@ class ConvGemmParams(C.Structure):
 
 class GroupNormParams(C.Structure):
     _fields_ = [("x", vp), ("x_ld", C.c_int), ("y", vp), ("y_ld", C.c_int), ("gamma", vp), ("beta", vp),
-                ("stats", vp), ("scratch", vp), ("chan_part", vp), ("part_ld", C.c_int),
+                ("stats", vp), ("scratch", vp), ("coef", vp), ("chan_part", vp), ("part_ld", C.c_int),
                 ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("eps", C.c_float), ("silu", C.c_int),
                 ("dy", vp), ("dy_ld", C.c_int), ("dx", vp), ("dx_ld", C.c_int), ("accumulate", C.c_int)]
 
@@ -80,7 +80,7 @@ class ConvF32Params(C.Structure):
 
 
 CF_BIAS, CF_RES, CF_RELU, CF_GEGLU, CF_OUT_F32, CF_MASK, CF_RES_F32, CF_GEGLU_RAW, CF_STATS = 1, 2, 4, 8, 16, 32, 64, 128, 256
-CF_LNFOLD, CF_ROWSTATS = 1024, 2048
+CF_LNFOLD, CF_ROWSTATS, CF_GNFOLD = 1024, 2048, 4096
 
 # every symbol declared in include/distdiff_hip_ops.h and include/distdiff_hip.h (checked by tests/test_abi.py)
 OPS_SYMBOLS = [

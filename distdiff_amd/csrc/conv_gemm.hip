@@ -359,8 +359,16 @@ bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int
   return true;
 }
 
+bool conv_gemm_can_fold_gn(ConvGemmParams p) {
+  p.flags |= CF_GNFOLD;
+  static float dummy;
+  if (!p.gn_coef) p.gn_coef = &dummy;
+  return conv_halo_config(p) != 0;
+}
+
 hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStream_t stream) {
   if (p.K & 63) return hipErrorInvalidValue;
+  if ((p.flags & CF_GNFOLD) && !conv_halo_config(p)) return hipErrorInvalidValue;
   if ((p.flags & CF_LNFOLD) && (!p.ln_stats || !p.ln_c1 || p.ntaps != 1)) return hipErrorInvalidValue;
   if (p.flags & CF_ROWSTATS) {
     int spans = 0;

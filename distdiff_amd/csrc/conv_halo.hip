@@ -168,6 +168,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const halo = smem + 2 * WB;
   float* const bias_s = (float*)(halo + ((halo_px + 7) & ~7) * 128);
+  float* const coef_s = bias_s + BN;                     // CF_GNFOLD: (a, b) of the chunk's 64 channels for this tile's image
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,6 +228,36 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     }
   };
 
+  // CF_GNFOLD: GroupNorm(+SiLU) applied to the staged halo chunk in place -- y = silu(x * a[c] + b[c]) on every pixel that lies inside
+  // the image (the zero padding stays zero) -- once per tile and chunk instead of a pass over the tensor in front of this convolution.
+  // The two row groups take alternate 256-vector slices; 16 bytes = 8 channels of one pixel per thread and step.
+  const bool gnf = (p.flags & CF_GNFOLD) != 0;
+  auto load_coef = [&](int chunk) {        // wave 0: 64 channels x (a, b)
+    if (wave == 0) *(float2*)(coef_s + lane * 2) = *(const float2*)(p.gn_coef + ((size_t)img * p.cin + chunk * 64 + lane) * 2);
+  };
+  auto apply_gn = [&](int g) {
+    const int nv = halo_px * 8;
+    for (int v = g * 256 + (tid & 255); v < nv; v += 512) {
+      const int hp = v >> 3, ps = v & 7;
+      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if (iy < 0 || iy >= p.Ho || ix < 0 || ix >= p.Wo) continue;
+      const int j = ps ^ (hx & 7);
+      uint4* px = (uint4*)(halo + v * 16);
+      float xv[8];
+      unpack8(*px, xv);
+      const float4 c0 = *(const float4*)(coef_s + j * 16), c1 = *(const float4*)(coef_s + j * 16 + 4);
+      const float4 c2 = *(const float4*)(coef_s + j * 16 + 8), c3 = *(const float4*)(coef_s + j * 16 + 12);
+      const float ca[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z}, cb[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = xv[e] * ca[e] + cb[e];
+        xv[e] = p.gn_silu ? silu_f(y) : y;
+      }
+      *px = pack8(xv);
+    }
+  };
+
   f32x4 acc[8][TN];
 #pragma unroll
   for (int a = 0; a < 8; ++a)
@@ -234,20 +265,35 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue
+  if (gnf) load_coef(0);
   if (grp == 0) issue_halo(0);
 #pragma unroll
   for (int i = 0; i < NWP; ++i) issue_w(0, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                      // also publishes bias_s
+  __syncthreads();                                      // also publishes bias_s / coef_s
+  if (gnf) { apply_gn(grp); __syncthreads(); }
   if (grp == 1) __builtin_amdgcn_s_barrier();           // the second group runs one barrier behind
 
   bf16x8 wf[TN][2], xf[2][2];
   int kt = 0;
   for (int c = 0; c < chunks; ++c) {
     if (c > 0) {
-      // every read of the previous chunk's halo has retired (both halves waited lgkmcnt(0) in front of their last X barrier)
-      if (grp == 0) { issue_halo(c); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      // every read of the previous chunk's halo has retired (both groups waited lgkmcnt(0) in front of their last X barrier)
+      if (grp == 0) {
+        if (gnf) load_coef(c);
+        issue_halo(c);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (gnf) {
+        // group 1 arrives here one barrier late, i.e. behind the barrier in front of which group 0 waited for the new halo: it applies
+        // its slice now, group 0 applies its own behind that same barrier, and the extra barrier below closes both
+        apply_gn(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
+      if (gnf) {
+        if (grp == 0) { apply_gn(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+      }
     }
     for (int t = 0; t < 9; ++t, ++kt) {
       const int e = __builtin_amdgcn_readlane(v_taps, t);
@@ -428,7 +474,7 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
 template <int TN, int WN>
 hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
-  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 64;
+  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
   const int tiles = (p.M / BM) * (p.N / BN);
@@ -445,7 +491,8 @@ int conv_halo_config(const ConvGemmParams& p) {
   if (!on || p.force_small) return 0;
   if (p.ntaps != 9 || p.stride != 1 || p.shift > 1 || p.parity || (p.H << p.shift) != p.Ho || (p.W << p.shift) != p.Wo || (p.cin & 63) ||
       p.K != 9 * p.cin) return 0;
-  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS)) || p.bias_sel) return 0;
+  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_GNFOLD)) || p.bias_sel) return 0;
+  if ((p.flags & CF_GNFOLD) && (!p.gn_coef || p.shift)) return 0;
   int tn = 0;
   if (p.N % 320 == 0) tn = 5; else if (p.N % 256 == 0) tn = 4; else if (p.N == 128) tn = 2;
   if (!tn) return 0;
@@ -457,7 +504,7 @@ int conv_halo_config(const ConvGemmParams& p) {
   if (p.ksplit > 1) return 0;
   const int tiles = (p.M / bm) * (p.N / bn);
   if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
-  if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 64 > 163840) return 0;
+  if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 512 + 64 > 163840) return 0;
   return tn;
 }
 

@@ -16,7 +16,7 @@ struct Run {
   dd_engine* E; hipStream_t s; int B;
   Ctx ctx(const Program& P, char* act) {
     Ctx c; c.act = act; c.grad = E->grad_slab; c.tr = E->tr_slab; c.tr_stride = P.tr_max; c.scratch_partial = E->scratch_partial; c.partial_cap = E->partial_cap;
-    c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.rowpart = E->rowpart; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
+    c.scratch_tmp = E->scratch_tmp; c.tmp_cap = E->tmp_cap; c.tap1x1 = E->tap1x1; c.gn_scratch = E->gn_scratch; c.rowpart = E->rowpart; c.gn_coef = E->gn_coef; c.s = s; c.B = B; c.cross_kv = &E->cross_kv; c.flops = &E->flops; c.prof = &E->prof;
     return c;
   }
 };
@@ -305,6 +305,13 @@ int dd_finalize_weights(dd_engine* E) {
     const int maxG = std::max(c.unet_groups, c.vae_groups);
     E->gn_scratch = (float*)E->dmalloc(groupnorm_scratch_bytes(2 * B, maxG), false);
     E->rowpart = (float*)E->dmalloc(std::max(E->unet.scratch_rowpart, (size_t)256), false);
+    {   // GroupNorm affine of the op that ran last (CF_GNFOLD): [images][channels][2] of the widest GroupNorm input
+      size_t n = 256;
+      for (const Program* P : {&E->unet, &E->vae, &E->venc})
+        for (const Op& o : P->ops)
+          if (o.kind == OP_GN) n = std::max(n, (size_t)P->t[o.x].B * P->t[o.x].C * 8);
+      E->gn_coef = (float*)E->dmalloc(n, false);
+    }
     for (auto& f : E->f32_tmp) f = (float*)E->dmalloc(zbytes);
     E->img_tmp = (float*)E->dmalloc((size_t)B * 3 * 64 * L * L * 4);
     E->score_tmp = (float*)E->dmalloc(256);

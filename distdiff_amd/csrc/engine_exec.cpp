@@ -59,6 +59,30 @@ void run_conv_f32_bwd(const Program& P, const Op& op, const Ctx& c) {
   HIPCHK(launch_conv_f32(p, c.s));
 }
 
+// forward launch parameters of a bf16 convolution / linear op (everything but the run-time fusion flags); `gn_in` >= 0: read the RAW
+// input of the GroupNorm op in front of it (CF_GNFOLD) instead of that op's output
+static void fwd_conv_params(const Program& P, const Op& op, const Ctx& c, ConvGemmParams& p, int gn_in = -1) {
+  const Tn& x = P.t[gn_in >= 0 ? gn_in : op.x_fwd >= 0 ? op.x_fwd : op.x]; const Tn& y = P.t[op.y];
+  fill_conv(p, c);
+  const ConvW* w = op.cw;
+  p.x = act_ptr(c, x); p.x_ld = x.ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
+  p.y = act_raw(c, y); p.y_ld = y.ld;
+  p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.shift = op.up; p.parity = 0;
+  p.cin = w->sf.cin; p.ntaps = w->sf.ntaps; p.M = y.rows; p.N = w->sf.N; p.K = w->sf.K;
+  int flags = 0;
+  if (op.use_table && w->bias_table) { flags |= CF_BIAS; p.bias = w->bias_table + (size_t)c.step_index * w->Cout; }
+  else if (w->bias) { flags |= CF_BIAS; p.bias = w->bias; }
+  if (op.res >= 0) { flags |= CF_RES; p.res = act_ptr(c, P.t[op.res]); p.res_ld = P.t[op.res].ld; }
+  if (op.relu) flags |= CF_RELU;
+  if (op.out_f32) flags |= CF_OUT_F32;
+  if (w->geglu) {
+    flags |= CF_GEGLU;
+    if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
+  }
+  if (op.ln_fold) { flags |= CF_LNFOLD; p.ln_stats = (const float*)(c.act + op.ln_stats_off); p.ln_c1 = w->ln_c1; }
+  p.flags = flags;
+}
+
 void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
   if (op_end < 0) op_end = (int)P.ops.size();
   if (c.prof) c.prof->new_run();
@@ -74,25 +98,13 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
     switch (op.kind) {
       case OP_CONV: {
         if (P.f32) { run_conv_f32_fwd(P, op, c); if (c.flops) *c.flops += op.flops; break; }
-        const Tn& x = P.t[op.x_fwd >= 0 ? op.x_fwd : op.x]; const Tn& y = P.t[op.y];
-        ConvGemmParams p; fill_conv(p, c);
+        // a GroupNorm(+SiLU) folded into this convolution (decided when the GroupNorm op ran: P.gn_folded): read its raw input
+        const int gfold = (op.gn_from >= 0 && P.gn_folded[op.gn_from]) ? P.ops[op.gn_from].x : -1;
+        const Tn& x = P.t[gfold >= 0 ? gfold : op.x_fwd >= 0 ? op.x_fwd : op.x]; const Tn& y = P.t[op.y];
         const ConvW* w = op.cw;
-        p.x = act_ptr(c, x); p.x_ld = x.ld; p.w = w->w_fwd; p.taptab = w->tap_fwd;
-        p.y = act_raw(c, y); p.y_ld = y.ld;
-        p.B = x.B; p.H = x.H; p.W = x.W; p.Ho = y.H; p.Wo = y.W; p.stride = op.stride; p.shift = op.up; p.parity = 0;
-        p.cin = w->sf.cin; p.ntaps = w->sf.ntaps; p.M = y.rows; p.N = w->sf.N; p.K = w->sf.K;
-        int flags = 0;
-        if (op.use_table && w->bias_table) { flags |= CF_BIAS; p.bias = w->bias_table + (size_t)c.step_index * w->Cout; }
-        else if (w->bias) { flags |= CF_BIAS; p.bias = w->bias; }
-        if (op.res >= 0) { flags |= CF_RES; p.res = act_ptr(c, P.t[op.res]); p.res_ld = P.t[op.res].ld; }
-        if (op.relu) flags |= CF_RELU;
-        if (op.out_f32) flags |= CF_OUT_F32;
-        if (w->geglu) {
-          flags |= CF_GEGLU;
-          if (op.raw >= 0 && c.stash) { flags |= CF_GEGLU_RAW; p.raw = act_ptr(c, P.t[op.raw]); p.raw_ld = P.t[op.raw].ld; }
-        }
-        if (op.ln_fold) { flags |= CF_LNFOLD; p.ln_stats = (const float*)(c.act + op.ln_stats_off); p.ln_c1 = w->ln_c1; }
-        p.flags = flags;
+        ConvGemmParams p;
+        fwd_conv_params(P, op, c, p, gfold);
+        if (gfold >= 0) { p.flags |= CF_GNFOLD; p.gn_coef = c.gn_coef; p.gn_silu = P.ops[op.gn_from].silu; }
         if (op.rowstat_emit) {
           // LayerNorm row partials for the op that follows: only when the kernel the launcher picks for this shape has the form
           p.rowpart = c.rowpart; p.rowpart_ld = op.rowstat_ld;
@@ -152,6 +164,15 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
         p.x = act_ptr(c, x); p.x_ld = x.ld; p.y = act_ptr(c, y); p.y_ld = y.ld;
         p.gamma = op.nw->gamma; p.beta = op.nw->beta; p.stats = (float*)(c.act + op.stats_off); p.scratch = c.gn_scratch;
         p.B = x.B; p.HW = x.H * x.W; p.C = x.C; p.G = op.G; p.eps = op.eps; p.silu = op.silu;
+        P.gn_folded[i] = 0;
+        if (op.gn_into >= 0 && c.gn_coef && !(c.img_bias > 0 && P.ops[op.gn_into].use_table && P.ops[op.gn_into].cw->bias_table_img)) {
+          // the only reader of this GroupNorm is the 3x3 convolution right behind it: when the launcher will run that convolution on
+          // the halo-resident kernel, the normalisation is applied to its staged input tile (CF_GNFOLD) and only the per-(image,
+          // channel) affine is produced here -- no pass over the tensor
+          ConvGemmParams q;
+          fwd_conv_params(P, P.ops[op.gn_into], c, q, op.x);
+          if (conv_gemm_can_fold_gn(q)) { p.coef = c.gn_coef; p.y = nullptr; P.gn_folded[i] = 1; }
+        }
         HIPCHK(launch_groupnorm_fwd(p, c.s));
       } break;
       case OP_LN: {

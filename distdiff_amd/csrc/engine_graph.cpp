@@ -269,6 +269,16 @@ void plan_gn_stats(Program& P) {
   check_transients(P);
   P.emitted.assign(P.ops.size(), 0);
   P.row_spans.assign(P.ops.size(), 0);
+  P.gn_folded.assign(P.ops.size(), 0);
+  // GroupNorm -> 3x3 convolution pairs (ResnetBlock2D: norm1 -> conv1, norm2 -> conv2; conv_norm_out -> conv_out): candidates for
+  // CF_GNFOLD.  The GroupNorm's output is a transient read by that convolution only (check_transients), so nothing else needs it.
+  if (!P.f32 && !getenv("DD_NO_GN_APPLY_FUSION"))
+    for (size_t gi = 0; gi + 1 < P.ops.size(); ++gi) {
+      Op& g = P.ops[gi]; Op& cv = P.ops[gi + 1];
+      if (g.kind != OP_GN || cv.kind != OP_CONV || cv.x != g.y || cv.x_fwd >= 0 || !P.t[g.y].transient) continue;
+      if (cv.cw->KH != 3 || cv.cw->KW != 3 || cv.stride != 1 || cv.up || cv.cw->f32 || cv.cw->geglu) continue;
+      g.gn_into = (int)gi + 1; cv.gn_from = (int)gi;
+    }
   if (P.f32 || getenv("DD_NO_GN_FUSION")) return;
   std::unordered_map<int, size_t> root_part;
   for (size_t gi = 0; gi < P.ops.size(); ++gi) {

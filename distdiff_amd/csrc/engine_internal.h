@@ -112,6 +112,9 @@ struct Op {
   // and the OP_CONV reads the LayerNorm's INPUT (x_fwd) with CF_LNFOLD; the backward plan is untouched (x stays the LayerNorm output)
   bool ln_fold = false; int x_fwd = -1; size_t ln_stats_off = 0;
   int rowstat_from = -1; bool rowstat_emit = false; int rowstat_ld = 0;
+  // GroupNorm(+SiLU) applied by the 3x3 convolution that follows (plan_gn_fold; decided per run, CF_GNFOLD): OP_GN.gn_into = that
+  // convolution's op index, OP_CONV.gn_from = the GroupNorm's
+  int gn_into = -1, gn_from = -1;
   double flops = 0;
 };
 
@@ -123,6 +126,7 @@ struct Program {
   bool want_grad = false;
   bool f32 = false;      // every activation AND gradient of this program is fp32 (the guide network, guide_f32.hip)
   mutable std::vector<char> emitted;   // per op, per forward run: this convolution did emit its GroupNorm partials
+  mutable std::vector<char> gn_folded; // per op, per forward run: this GroupNorm only produced its affine, the next convolution applies it
   mutable std::vector<int> row_spans;  // per op, per forward run: column spans of the LayerNorm row partials this GEMM emitted (0 = none)
   size_t scratch_rowpart = 0;          // bytes of the shared row-partial buffer (producer GEMM -> LayerNorm statistics, adjacent ops)
   size_t tr_max = 0;     // bytes of one transient ping-pong buffer
@@ -198,6 +202,7 @@ struct Ctx {  // per-call execution context
   char* scratch_tmp = nullptr;
   float* gn_scratch = nullptr;
   float* rowpart = nullptr;      // LayerNorm row partials of the GEMM that ran last (CF_ROWSTATS)
+  float* gn_coef = nullptr;      // GroupNorm affine [B][C][2] of the op that ran last (CF_GNFOLD)
   const int* tap1x1 = nullptr;   // device int: the 1x1 tap, for GEMMs issued outside a ConvW (wide-head attention)
   size_t tmp_cap = 0;
   int step_index = 0;
@@ -270,6 +275,7 @@ struct dd_engine {
   char* scratch_tmp = nullptr; size_t tmp_cap = 0;
   float* gn_scratch = nullptr;
   float* rowpart = nullptr;
+  float* gn_coef = nullptr;
   int* tap1x1 = nullptr;
   float* f32_tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B,4,L,L] fp32 temporaries
   float* img_tmp = nullptr;    // [B,3,8L,8L] fp32

@@ -29,6 +29,9 @@ enum ConvFlags {
                      // whose beta into the bias (b' = b + W beta): out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n] with
                      // c1[n] = sum_k W'[n, k] (of the bf16-rounded W'), (mean, rstd) = ln_stats[m] -- LayerNorm(x) W^T + b without ever
                      // materialising LayerNorm(x).  Pointwise (1x1 / linear) layers only.
+  CF_GNFOLD = 4096,  // the input is the RAW input x of a GroupNorm(+SiLU): the halo-resident 3x3 kernel applies silu(x * a[b, c] + b[b, c]) to its
+                     // staged input tile (once per tile and 64-channel chunk, zero padding kept) instead of a separate apply pass; gn_coef =
+                     // per-(image, channel) (a, b) = (rstd * gamma, beta - mean * rstd * gamma).  conv_gemm_can_fold_gn() says when.
   CF_ROWSTATS = 2048 // also emit, per output row and per 80-/64-column wave span, (sum v, sum v^2) of the stored values into rowpart: the
                      // LayerNorm that consumes this tensor takes its row statistics from there (conv_gemm_can_emit_rowstats)
 };
@@ -47,8 +50,9 @@ struct ConvGemmParams {
   float* stats;         // CF_STATS: [M / 64][stats_ld][2] fp32 (mean, M2 of 64 rows), already offset to this op's first channel
   const float* ln_stats;// CF_LNFOLD: [M][2] fp32 (mean, rstd) of the LayerNorm's input rows
   const float* ln_c1;   // CF_LNFOLD: [N] fp32 column sums of the folded weights (packed order for GEGLU)
+  const float* gn_coef; // CF_GNFOLD: [B][cin][2] fp32 (a, b) per image and input channel
   float* rowpart;       // CF_ROWSTATS: [M][rowpart_ld][2] fp32 (sum, sum of squares) per row and column span of conv_gemm_rowstat_span(N)
-  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride, stats_ld, rowpart_ld;
+  int x_ld, y_ld, res_ld, mask_ld, raw_ld, bias_stride, stats_ld, rowpart_ld, gn_silu;
   int B, H, W;          // stored input geometry
   int Ho, Wo;           // output geometry
   int stride;           // output->logical-input stride (1 or 2)
@@ -72,6 +76,9 @@ bool conv_gemm_can_emit_stats(ConvGemmParams p, size_t partial_cap_bytes);
 // CF_ROWSTATS: true iff launch_conv_gemm will honour it for this problem; *spans = number of (sum, sum^2) pairs per row it writes
 // (N / columns per wave of the tile the launcher picks); rowpart_ld must be >= *spans
 bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int* spans);
+// CF_GNFOLD: true iff launch_conv_gemm will send this problem to the halo-resident 3x3 kernel (the only form that can apply a GroupNorm
+// to its input tile)
+bool conv_gemm_can_fold_gn(ConvGemmParams p);
 
 // ----------------------------------------------------------------------------------------------
 // K3: GroupNorm (+ optional SiLU) forward / backward on NHWC bf16.
@@ -82,6 +89,8 @@ struct GroupNormParams {
   const float* gamma; const float* beta;   // [C]
   float* stats;        // [B][G][2] (mean, rstd), written by fwd, read by bwd
   float* scratch;      // [B][S][G][3] partial (count, mean, M2) / bwd partial sums
+  float* coef;             // fwd, optional: instead of applying, write the per-(image, channel) affine (a, b) [B][C][2] for a consumer
+                           //   that applies it itself (CF_GNFOLD); y is then unused
   const float* chan_part;  // fwd, optional: per-(64-row block, channel) partials (mean, M2) emitted by the producing convolutions
   int part_ld;             //   (CF_STATS), [B*HW/64][part_ld][2], already offset to channel 0 of x: replaces the statistics pass
   int B, HW, C, G;

@@ -213,6 +213,17 @@ __global__ __launch_bounds__(GN_THREADS) void gn_finalize_chan_kernel(GroupNormP
   }
 }
 
+// Instead of pass 3 when the consumer applies the normalisation itself (CF_GNFOLD): the per-(image, channel) affine y = x * a + b
+__global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(GroupNormParams p) {
+  const int b = blockIdx.x, cpg = p.C / p.G;
+  for (int c = threadIdx.x; c < p.C; c += GN_THREADS) {
+    const int g = c / cpg;
+    const float mean = p.stats[((size_t)b * p.G + g) * 2], rstd = p.stats[((size_t)b * p.G + g) * 2 + 1];
+    const float a = rstd * p.gamma[c];
+    *(float2*)(p.coef + ((size_t)b * p.C + c) * 2) = make_float2(a, p.beta[c] - mean * a);
+  }
+}
+
 // Pass 3: build the per-channel affine in LDS, stream the tensor (4 vectors in flight per thread).
 template <bool BWD>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GroupNormParams p, const float* fin) {
@@ -490,13 +501,17 @@ static hipError_t gn_launch(const GroupNormParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gn_partial_kernel<BWD>), dim3(S, p.B), dim3(GN_THREADS), gn_partial_lds(p.C), stream, p);
     hipLaunchKernelGGL((gn_finalize_kernel<BWD>), dim3((p.B * p.G + 3) / 4), dim3(GN_THREADS), 0, stream, p, S, fin);
   }
+  if (!BWD && p.coef) {
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(p.B), dim3(GN_THREADS), 0, stream, p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((gn_apply_kernel<BWD>), dim3(gn_apply_blocks(p), p.B), dim3(GN_THREADS), (BWD ? 6 : 2) * p.C * sizeof(float), stream, p,
                      (const float*)fin);
   return hipGetLastError();
 }
 
 hipError_t launch_groupnorm_fwd(const GroupNormParams& p, hipStream_t stream) {
-  if (gn_check(p) != hipSuccess || (p.y_ld & 7)) return hipErrorInvalidValue;
+  if (gn_check(p) != hipSuccess || (!p.coef && (p.y_ld & 7))) return hipErrorInvalidValue;
   return gn_launch<false>(p, stream);
 }
 

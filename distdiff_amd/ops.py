@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_LNFOLD, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, CF_ROWSTATS, CF_STATS, AttnParams,
+from ._lib import (CF_BIAS, CF_GEGLU, CF_GEGLU_RAW, CF_GNFOLD, CF_LNFOLD, CF_MASK, CF_OUT_F32, CF_RELU, CF_RES, CF_RES_F32, CF_ROWSTATS, CF_STATS, AttnParams,
                    ConvGemmParams, GroupNormParams, LayerNormParams, check)
 
 
@@ -102,7 +102,7 @@ def conv_f32(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask
 
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
               ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False, stats=None, ln_stats=None, ln_c1=None,
-              rowpart=None):
+              rowpart=None, gn_coef=None, gn_silu=True):
     """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)].  stats: fp32 [M/64, C, 2] buffer (or a column view of one) to
     receive the per-(64-row block, channel) partial (mean, M2) of the stored values (CF_STATS; the launch fails if the kernel the
     launcher picks for this shape cannot emit them)."""
@@ -149,6 +149,9 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
     if ln_stats is not None:      # CF_LNFOLD: x is the raw LayerNorm input, pk holds gamma o W, ln_c1 its column sums (packed order)
         flags |= CF_LNFOLD
         p.ln_stats, p.ln_c1 = _ptr(ln_stats), _ptr(ln_c1)
+    if gn_coef is not None:       # CF_GNFOLD: x is the raw GroupNorm input, gn_coef fp32 [B, Cin, 2] = (a, b) per image and channel
+        flags |= CF_GNFOLD
+        p.gn_coef, p.gn_silu = _ptr(gn_coef), int(gn_silu)
     if rowpart is not None:       # CF_ROWSTATS: fp32 [M, spans, 2] (sum, sum of squares) per row and column span
         flags |= CF_ROWSTATS
         p.rowpart, p.rowpart_ld = _ptr(rowpart), rowpart.stride(0) // 2
@@ -156,6 +159,22 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
     p.force_small = int(force_small)
     check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
     return y
+
+
+def groupnorm_coef(x, gamma, beta, B, HW, G, eps):
+    """The per-(image, channel) affine of a GroupNorm, fp32 [B, C, 2] = (rstd * gamma, beta - mean * rstd * gamma), for a consumer
+    that applies it itself (CF_GNFOLD); also returns the (mean, rstd) statistics."""
+    Cc = x.shape[1]
+    L = _lib.lib()
+    p = GroupNormParams()
+    scratch = torch.empty((L.dd_op_groupnorm_scratch_bytes(B, G) // 4,), device=x.device, dtype=torch.float32)
+    stats = torch.empty((B, G, 2), device=x.device, dtype=torch.float32)
+    coef = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+    p.x, p.x_ld = _ptr(x), x.stride(0)
+    p.gamma, p.beta, p.stats, p.scratch, p.coef = _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(scratch), _ptr(coef)
+    p.B, p.HW, p.C, p.G, p.eps, p.silu = B, HW, Cc, G, eps, 0
+    check(L.dd_op_groupnorm_fwd(C.byref(p), _stream()), "gn_coef")
+    return coef, stats
 
 
 def groupnorm(x, gamma, beta, B, HW, G, eps, silu, dy=None, stats=None, chan_part=None):

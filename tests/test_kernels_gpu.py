@@ -148,6 +148,32 @@ def test_conv_general_staging_path_beyond_4gb(ops):
         assert_close(got, ref, what="general path, image %d" % b)
 
 
+@pytest.mark.parametrize("case", [("gnfold_320_32x32", 48, 320, 320, 32, 32, 32, True), ("gnfold_256_64x64_res", 12, 128, 256, 64, 64, 32, True),
+                                  ("gnfold_n128_nosilu", 1, 64, 128, 256, 512, 32, False)], ids=lambda c: c[0])
+def test_groupnorm_applied_by_the_halo_convolution(ops, case):
+    """CF_GNFOLD: GroupNorm(+SiLU) -> 3x3 convolution (ResnetBlock2D norm1 -> conv1, norm2 -> conv2) with the normalisation applied to
+    the convolution's staged input tile instead of a pass over the tensor: same result as GroupNorm -> conv through the separate
+    kernels (the affine, SiLU and bf16 rounding are the same arithmetic) and as torch on the same bf16 inputs."""
+    name, B, Cin, Cout, H, W, G, silu = case
+    g = torch.Generator().manual_seed(len(name))
+    x = bf(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.4)
+    gamma, beta = 1.0 + 0.2 * torch.randn(Cin, generator=g), 0.3 * torch.randn(Cin, generator=g)
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    bias = torch.randn(Cout, generator=g)
+    hn = F.group_norm(x, G, gamma, beta, 1e-5)
+    ref = F.conv2d(bf(F.silu(hn) if silu else hn), w, bias, padding=1)
+    xd = ops.to_nhwc_bf16(x, Cin).cuda()
+    pk = ops.PackedConv(w, 1, mode=0, bias=bias)
+    coef, stats = ops.groupnorm_coef(xd, gamma.cuda(), beta.cuda(), B, H * W, G, 1e-5)
+    y = ops.conv_gemm(xd, pk, B, H, W, H, W, gn_coef=coef, gn_silu=silu)
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(y, B, H, W), ref, what=name + " vs torch")
+    yn, _ = ops.groupnorm(xd, gamma.cuda(), beta.cuda(), B, H * W, G, 1e-5, silu)
+    y2 = ops.conv_gemm(yn, pk, B, H, W, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), y2.cpu()), "folded and separate GroupNorm -> conv differ bitwise"
+
+
 def test_linear_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, K, N = 300, 320, 640
