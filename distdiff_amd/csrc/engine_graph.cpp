@@ -272,7 +272,10 @@ void plan_gn_stats(Program& P) {
   P.gn_folded.assign(P.ops.size(), 0);
   // GroupNorm -> 3x3 convolution pairs (ResnetBlock2D: norm1 -> conv1, norm2 -> conv2; conv_norm_out -> conv_out): candidates for
   // CF_GNFOLD.  The GroupNorm's output is a transient read by that convolution only (check_transients), so nothing else needs it.
-  if (!P.f32 && !getenv("DD_NO_GN_APPLY_FUSION"))
+  // Built, bit-identical to the separate kernels (tests/test_kernels_gpu.py::test_groupnorm_applied_by_the_halo_convolution) and
+  // OFF by default: the apply runs once per tile, 64-channel chunk and n-tile while the matrix pipe waits (norm family 206 -> 155 ms,
+  // conv family 1615 -> 1673 ms per 32-image step, same device, tools/ab_gn.sh): DD_GN_APPLY_FUSION=1 switches it on.
+  if (!P.f32 && getenv("DD_GN_APPLY_FUSION") && atoi(getenv("DD_GN_APPLY_FUSION")))
     for (size_t gi = 0; gi + 1 < P.ops.size(); ++gi) {
       Op& g = P.ops[gi]; Op& cv = P.ops[gi + 1];
       if (g.kind != OP_GN || cv.kind != OP_CONV || cv.x != g.y || cv.x_fwd >= 0 || !P.t[g.y].transient) continue;
