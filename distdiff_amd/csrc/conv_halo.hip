@@ -358,6 +358,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 // (tools/micro/pingpong_gemm.hip): 320 x 320 at M = 262144 103 us vs 140 us, 640 x 640 62 vs 96, 1280 x 1280 50 vs 72, ff.net.2
 // 320 x 1280 232 vs 325 us.
 // ------------------------------------------------------------------------------------------------------------------------------------
+#ifdef DD_TRACE
+// debug build only (tools/pp_trace.py): per workgroup (entry, K loop start, K loop end, exit) in s_memrealtime ticks (10 ns) + HW_ID / XCC_ID
+__device__ unsigned long long g_pp_trace[8192 * 6];
+#define PP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_pp_trace[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
 template <int TN>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
   constexpr int BM = 256, BN = 4 * TN * 16;
@@ -371,6 +378,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
+  PP_STAMP(0);
+#ifdef DD_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    g_pp_trace[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    g_pp_trace[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
   int tile;
   {
     const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -410,6 +424,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
   for (int q = 0; q < NP; ++q) issue(0, q);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PP_STAMP(1);
   if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
   bf16x8 wf[TN][2], xf[2][2];
   for (int kt = 0; kt < KT; ++kt) {
@@ -456,8 +471,220 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
+  PP_STAMP(2);
   auto m_of = [&](int r) { return m0 + r; };
   pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, c1_s, (n0 / BN) * 4 + wc, fr, fq);
+  PP_STAMP(3);
+}
+
+// GEGLU epilogue of the persistent ping-pong GEMM (TN = 4: a wave owns two packed (16 hidden | 16 gate) groups).  The weight rows are
+// assigned to MFMA rows so that a lane holds, per 16-row tile, the hidden AND gate pre-activations of 8 consecutive output columns
+// (fq * 8 .. + 7 of the wave's 32): 16-byte stores of the product and of both halves of the CF_GEGLU_RAW stash.  bias / c1 in packed order.
+template <class MOf>
+__device__ __forceinline__ void pp_epilogue_geglu(const ConvGemmParams& p, f32x4 (&acc)[8][4], MOf m_of, int wr, int wc, int n0,
+                                                  const float* bias_s, const float* c1_s, int fr, int fq) {
+  const int fl = p.flags;
+  const int pk = wc * 64 + (fq >> 1) * 32 + (fq & 1) * 8;      // packed column (inside the tile) of this lane's first hidden value
+  float4 bh[2], bg[2], ch[2], cg[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bh[t] = *(const float4*)(bias_s + pk + t * 4); bg[t] = *(const float4*)(bias_s + pk + 16 + t * 4);
+    ch[t] = *(const float4*)(c1_s + pk + t * 4); cg[t] = *(const float4*)(c1_s + pk + 16 + t * 4);
+  }
+  const int oc = (n0 >> 1) + wc * 32 + fq * 8;                  // output column of the lane's 8 products
+#pragma unroll
+  for (int a2 = 0; a2 < 8; a2 += 2) {
+    float2 lst[2];
+    int mrow[2];
+#pragma unroll
+    for (int a4 = 0; a4 < 2; ++a4) {
+      mrow[a4] = m_of(wr * 128 + (a2 + a4) * 16 + fr);
+      lst[a4] = (fl & CF_LNFOLD) ? *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2) : make_float2(0.f, 1.f);
+    }
+#pragma unroll
+    for (int a4 = 0; a4 < 2; ++a4) {
+      const int a = a2 + a4, m = mrow[a4];
+      const float rs = lst[a4].y * p.alpha, nm = -lst[a4].y * lst[a4].x;
+      float h[8], g[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float bhv[4] = {bh[t].x, bh[t].y, bh[t].z, bh[t].w}, bgv[4] = {bg[t].x, bg[t].y, bg[t].z, bg[t].w};
+        const float chv[4] = {ch[t].x, ch[t].y, ch[t].z, ch[t].w}, cgv[4] = {cg[t].x, cg[t].y, cg[t].z, cg[t].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[t * 4 + r] = __builtin_fmaf(rs, acc[a][2 * t][r], __builtin_fmaf(nm, chv[r], bhv[r]));
+          g[t * 4 + r] = __builtin_fmaf(rs, acc[a][2 * t + 1][r], __builtin_fmaf(nm, cgv[r], bgv[r]));
+        }
+      }
+      if (fl & CF_GEGLU_RAW) {
+        bf16_t* rp = p.raw + (size_t)m * p.raw_ld + n0 + pk;
+        *(uint4*)rp = pack8(h);
+        *(uint4*)(rp + 16) = pack8(g);
+      }
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = h[e] * gelu_f(g[e]);
+      *(uint4*)((bf16_t*)p.y + (size_t)m * p.y_ld + oc) = pack8(o);
+    }
+  }
+}
+
+// The same ping-pong K loop for pointwise (1x1 / linear) layers, PERSISTENT: 256 x (64 TN) tiles, both operands streamed through two
+// 64-deep stages (TN = 5: A 32 KB + W 40 KB per K-step, 6.9 B per kFLOP against 13.8 for the 128 x 160 two-workgroup form, every A
+// row read once).  One workgroup per CU walks its share of the tiles (an XCD owns a contiguous range, n-tiles fastest, dealt round-robin
+// to its workgroups); the first K-step of the NEXT tile (and its bias / c1 rows, 16-byte LDS-DMA pieces into a two-slot ring) is
+// requested during the last K-step of the current one, so launch, prologue latency and the drain of the epilogue's stores no longer sit
+// between two K loops (tools/pp_trace.py: 2.9 + 1.1 us of a 21 us tile at K = 320).  GEGLU: TN = 4 with the packed (hidden | gate) epilogue.
+// ------------------------------------------------------------------------------------------------------------------------------------
+#ifdef DD_TRACE
+#define PPS_STAMP(t, i) do { if (threadIdx.x == 0 && (t) < 8192) g_pp_trace[(t) * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PPS_STAMP(t, i) do { } while (0)
+#endif
+template <int TN, bool GEGLU>
+__global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
+  constexpr int BM = 256, BN = 4 * TN * 16;
+  constexpr int BUF = (BM + BN) * 128;
+  constexpr int NP = 4 + TN;                           // pieces per wave and K-step: 4 of A, TN of W
+  constexpr int AUX = 2 * BUF;                         // [slot][bias 2 KB | c1 2 KB]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
+  // this workgroup's tiles: first, first + per, ... (count of them) inside its XCD's contiguous range
+  int first, count;
+  const int per = gridDim.x >> 3;
+  {
+    const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xbase = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, xcount = q + (xcd < r ? 1 : 0);
+    first = xbase + slot;
+    count = slot < xcount ? (xcount - slot + per - 1) / per : 0;
+  }
+  if (count == 0) return;
+  const int KT = p.K >> 6;
+  const int prow = lane >> 3, j = (lane & 7) ^ prow;
+  constexpr int TNP = TN & ~1;
+  unsigned aoff[4], woff[TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)((wave + 8 * i) * 8 + prow) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int R = (wave + 8 * i) * 8 + prow;             // MFMA-ordered row of the W stage -> weight row of the tile
+    const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
+    int ch;
+    if (GEGLU) {
+      const int c = (f >> 2) * 8 + (jn >> 1) * 4 + (f & 3);          // output column inside the wave's 32
+      ch = wv * 64 + (c >> 4) * 32 + (jn & 1) * 16 + (c & 15);
+    } else {
+      ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
+    }
+    woff[i] = ((unsigned)ch * (unsigned)p.K + (unsigned)(j * 8)) * 2u;
+  }
+  // bias / c1 pieces of a tile: waves 0, 1 bring bias[n0 .. n0 + BN), waves 2, 3 c1 (256 floats per piece; absent rows read as zeros)
+  const unsigned auxoff = (wave < 4 && (wave & 1) * 256 + lane * 4 < BN && ((wave < 2) ? (p.flags & CF_BIAS) : (p.flags & CF_LNFOLD)))
+                              ? (unsigned)((wave & 1) * 256 + lane * 4) * 4u : 0xffffff00u;
+  const float* auxbase = wave < 2 ? p.bias : p.ln_c1;
+  // piece `which` of K-step kt of the tile at (xt, n0) into stage `buf`
+  auto issue = [&](const bf16_t* xt, unsigned wsoff, int kt, int buf, int which) {
+    unsigned char* b = smem + buf * BUF;
+    if (which < 4) hdma16(xt, b + (wave + 8 * which) * 1024, aoff[which], (unsigned)kt * 128u);
+    else hdma16(p.w, b + BM * 128 + (wave + 8 * (which - 4)) * 1024, woff[which - 4], wsoff + (unsigned)kt * 128u);
+  };
+  auto issue_aux = [&](int n0, int slot) {
+    if (wave < 4) hdma16(auxbase ? (const void*)auxbase : (const void*)p.w, smem + AUX + slot * 4096 + (wave >> 1) * 2048 + (wave & 1) * 1024, auxoff, (unsigned)n0 * 4u);
+  };
+  int tile = first;
+  int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const bf16_t* xt = p.x + (size_t)m0 * p.x_ld;          // per-tile base: 32-bit byte offsets only span 256 rows
+  unsigned wsoff = (unsigned)n0 * (unsigned)p.K * 2u;
+  int cur = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) issue(xt, wsoff, 0, 0, q);
+  issue_aux(n0, 0);
+  f32x4 acc[8][TN];
+  bf16x8 wf[TN][2], xf[2][2];
+  for (int it = 0; it < count; ++it) {
+    PPS_STAMP(tile, 0);
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // next tile (wave-uniform)
+    const bool have_next = it + 1 < count;
+    const int tile_n = tile + per;
+    const int m0n = (tile_n / ntn) * BM, n0n = (tile_n % ntn) * BN;
+    const bf16_t* xtn = p.x + (size_t)m0n * p.x_ld;
+    const unsigned wsoffn = (unsigned)n0n * (unsigned)p.K * 2u;
+    // the first K-step of this tile was requested before the previous tile's epilogue (a counted wait that leaves the epilogue's last
+    // stores in flight measured the same: what is left here is the skew between the eight waves' epilogues, tools/pp_trace.py)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PPS_STAMP(tile, 1);
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
+    for (int kt = 0; kt < KT; ++kt) {
+      const unsigned char* Ab = smem + cur * BUF;
+      const unsigned char* Bb = Ab + BM * 128;
+      const bool more = kt + 1 < KT;
+      const bool pre = more || have_next;
+      const bf16_t* nx = more ? xt : xtn;
+      const unsigned nw = more ? wsoff : wsoffn;
+      const int nk = more ? kt + 1 : 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s == 0) {
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int row = wc * (TN * 16) + jn * 16 + fr;
+              wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int row = wr * 128 + s * 32 + i * 16 + fr;
+            xf[i][ks] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+          }
+        if (s < 3 && pre) {
+          constexpr int PP = (NP + 2) / 3;
+#pragma unroll
+          for (int q = 0; q < PP; ++q)
+            if (s * PP + q < NP) issue(nx, nw, nk, cur ^ 1, s * PP + q);
+          if (s == 2 && !more) issue_aux(n0n, (it + 1) & 1);
+        }
+        if (s == 3) {
+          if (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      cur ^= 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    PPS_STAMP(tile, 2);
+    const float* bias_s = (const float*)(smem + AUX + (it & 1) * 4096);
+    const int m0c = m0;
+    auto m_of = [&](int r) { return m0c + r; };
+    if constexpr (GEGLU) pp_epilogue_geglu(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, fr, fq);
+    else pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, (n0 / BN) * 4 + wc, fr, fq);
+    PPS_STAMP(tile, 3);
+    tile = tile_n; m0 = m0n; n0 = n0n; xt = xtn; wsoff = wsoffn;
+  }
 }
 
 bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
@@ -508,27 +735,57 @@ int conv_halo_config(const ConvGemmParams& p) {
   return tn;
 }
 
-// pointwise ping-pong GEMM: 0 = not eligible, else TN (5: 256 x 320 tiles)
+// pointwise ping-pong GEMM: 0 = not eligible, else TN (5: 256 x 320 tiles; 4: 256 x 256 tiles of a GEGLU projection)
 int gemm_pp_config(const ConvGemmParams& p) {
   static const int on = getenv("DD_GEMM_PP") ? atoi(getenv("DD_GEMM_PP")) : 1;
+  static const int geglu_on = getenv("DD_GEMM_PP_GEGLU") ? atoi(getenv("DD_GEMM_PP_GEGLU")) : 1;
+  static const int nmax = getenv("DD_GEMM_PP_NMAX") ? atoi(getenv("DD_GEMM_PP_NMAX")) : 3840;
   if (!on || p.force_small) return 0;
   if (p.ntaps != 1 || p.stride != 1 || p.shift || p.parity || p.H != p.Ho || p.W != p.Wo || (p.cin & 63) || p.K != p.cin) return 0;
-  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_ROWSTATS | CF_LNFOLD)) || p.bias_sel) return 0;
-  if (p.N % 320 || p.N > 1280 || (p.M & 255) || p.K < 256 || p.ksplit > 1) return 0;
-  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7)) return 0;
-  if ((size_t)256 * p.x_ld * 2 >= 0xF0000000ull) return 0;
+  if ((p.M & 255) || p.K < 256 || p.ksplit > 1 || p.bias_sel || (p.x_ld & 7) || (p.y_ld & 7)) return 0;
+  if ((size_t)256 * p.x_ld * 2 >= 0xF0000000ull || (size_t)p.N * p.K * 2 >= 0xF0000000ull) return 0;
+  if (p.flags & CF_GEGLU) {
+    if (!geglu_on || on == 2) return 0;
+    if (p.flags & ~(CF_BIAS | CF_GEGLU | CF_GEGLU_RAW | CF_LNFOLD)) return 0;
+    if ((p.N & 255) || ((p.flags & CF_GEGLU_RAW) && (p.raw_ld & 7))) return 0;
+    if ((p.M / 256) * (p.N / 256) < 192) return 0;
+    return 4;
+  }
+  if (p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_ROWSTATS | CF_LNFOLD)) return 0;
+  if (p.N % 320 || p.N > nmax) return 0;
+  if ((p.flags & CF_RES) && (p.res_ld & 7)) return 0;
   if ((p.M / 256) * (p.N / 320) < 192) return 0;
   return 5;
 }
+template <int TN, bool GEGLU>
+static hipError_t run_pps(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr int BN = 64 * TN;
+  const int lds = 2 * (256 + BN) * 128 + 2 * 4096;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)gemm_pps_kernel<TN, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  static const int cus = [] { int d = 0, n = 256; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 8 ? n & ~7 : 8; }();
+  const int tiles = (p.M / 256) * (p.N / BN);
+  const int grid = tiles >= cus ? cus : (tiles + 7) & ~7;
+  hipLaunchKernelGGL((gemm_pps_kernel<TN, GEGLU>), dim3(grid), dim3(512), lds, stream, p);
+  return hipGetLastError();
+}
 hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream) {
-  constexpr int BN = 320;
+  static const int mode = getenv("DD_GEMM_PP") ? atoi(getenv("DD_GEMM_PP")) : 1;
+  if (tn == 4) return run_pps<4, true>(p, stream);
+  if (mode != 2) return run_pps<5, false>(p, stream);
+  constexpr int BN = 320;                                // DD_GEMM_PP=2: the one-tile-per-workgroup form (A/B)
   const int lds = 2 * (256 + BN) * 128 + 2 * BN * 4 + 64;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)gemm_pp_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-  (void)tn;
   hipLaunchKernelGGL((gemm_pp_kernel<5>), dim3((p.M / 256) * (p.N / BN)), dim3(512), lds, stream, p);
   return hipGetLastError();
 }
+
+#ifdef DD_TRACE
+extern "C" int dd_debug_read_pp_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
   HaloGeo g;

@@ -217,7 +217,7 @@ def test_pointwise_launch_requires_the_centre_tap(ops):
         ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
 
 
-@pytest.mark.parametrize("M,K,Fd", [(200, 128, 256), (1500, 320, 1280)])
+@pytest.mark.parametrize("M,K,Fd", [(200, 128, 256), (1500, 320, 1280), (12288, 320, 512), (16384, 640, 1280)])   # the last two: persistent ping-pong GEMM, 256 x 256 tiles
 def test_geglu_forward_backward(ops, M, K, Fd):
     from distdiff_amd import _lib
     g = torch.Generator().manual_seed(4)
@@ -285,13 +285,15 @@ def test_layernorm(ops, Cc):
 
 
 @pytest.mark.parametrize("M,Cc,N,geglu", [(4096, 320, 960, False), (2048, 640, 640, False), (4096, 320, 2560, True), (300, 320, 320, False),
-                                            (1024, 1280, 3840, False), (49152, 320, 960, False), (49152, 640, 640, False)])
+                                            (1024, 1280, 3840, False), (49152, 320, 960, False), (49152, 640, 640, False),
+                                            (12288, 320, 1024, True), (24576, 640, 2560, True)])
 def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
     """CF_LNFOLD: LayerNorm(x) W^T + b computed as rstd * (x (gamma o W)^T - mean * c1) + (b + W beta) from the RAW x and the row
     statistics -- the transformer blocks' LayerNorm -> QKV / to_q / GEGLU projections (diffusers BasicTransformerBlock).
     Checked against torch's layer_norm + linear on the same bf16 inputs (the folded form never rounds LayerNorm(x) to bf16, so it is
     the more accurate of the two); M = 300 takes the small kernel's generic epilogue, M = 49152 (>= 192 tiles of 256 rows, N <= 1280) the
-    ping-pong GEMM of conv_halo.hip, the others the batched two-workgroup forms."""
+    ping-pong GEMM of conv_halo.hip (GEGLU: its 256 x 256 form, a ragged number of tiles per persistent workgroup), the others the batched
+    two-workgroup forms."""
     g = torch.Generator().manual_seed(77)
     x = bf(torch.randn(M, Cc, generator=g) * 1.7 + torch.randn(M, 1, generator=g) * 0.8)      # row means of the size of the row std
     gamma, beta = 1.0 + 0.3 * torch.randn(Cc, generator=g), 0.2 * torch.randn(Cc, generator=g)
