@@ -162,7 +162,8 @@ template <int TN, int WN>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, HaloGeo geo) {
   const int lw = geo.ltw, halo_px = geo.halo_px;
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
-  constexpr int NWP = BN / 64;                          // weight pieces (8 rows x 128 B) per wave and K-step
+  constexpr int NPC = BN / 8;                           // weight pieces (8 rows x 128 B) per K-step
+  constexpr int NWP = (NPC + 7) / 8;                    // ... per wave (the last one only on the first NPC % 8 waves when BN % 64 != 0)
   constexpr int WB = BN * 128;                          // bytes of one weight stage
   constexpr unsigned OOB = 0xfffffff0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,10 +208,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     const int R = (wave + 8 * i) * 8 + prow;
     const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
     const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
-    woff[i] = ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u;
+    woff[i] = ((NPC & 7) == 0 || R < BN) ? ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u : OOB;
   }
   auto issue_w = [&](int kt, int i) {
-    hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)kt * 128u);
+    if ((NPC & 7) == 0 || wave + 8 * i < NPC) hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)kt * 128u);
   };
   // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
   const float inv_w2 = 1.f / (float)W2;
@@ -274,7 +275,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   if (gnf) { apply_gn(grp); __syncthreads(); }
   if (grp == 1) __builtin_amdgcn_s_barrier();           // the second group runs one barrier behind
 
-  bf16x8 wf[TN][2], xf[2][2];
+  // Two sections per K-step, one per 32-deep K half: 8 x TN MFMAs between two barriers (the barrier hand-off between the SIMD partners is
+  // not hidden by anything: tools/micro/pingpong_gemm.hip, four 32-row strips per K-step cost 0.5 us of barrier skeleton per K-step,
+  // two K halves 0.35), TN + 8 fragments live instead of 2 TN + 4.
+  bf16x8 wf[TN], xf[8];
   int kt = 0;
   for (int c = 0; c < chunks; ++c) {
     if (c > 0) {
@@ -301,46 +305,37 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
       const int tapoff = dy * W2 + dx;
       const unsigned char* Bb = smem + (kt & 1) * WB;
       const bool more = kt + 1 < KT;
+      const int xs = (fr + 1 + dx) & 7;                   // 16-pixel row tiles start at multiples of 16 inside an image row (tw >= 16)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {                     // 32-row strips of this wave's 128 rows
+      for (int ks = 0; ks < 2; ++ks) {
         // ---- load section (the SIMD partner is in its MFMA section)
-        if (s == 0) {
 #pragma unroll
-          for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              const int row = wc * (TN * 16) + jn * 16 + fr;
-              wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-            }
+        for (int jn = 0; jn < TN; ++jn) {
+          const int row = wc * (TN * 16) + jn * 16 + fr;
+          wf[jn] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = wr * 128 + s * 32 + i * 16 + fr;
-          const int hp = r + 2 * (r >> lw) + Wd + 3 + tapoff;          // halo pixel of output pixel r for this tap
-          const int xs = ((r & (Wd - 1)) + 1 + dx) & 7;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) xf[i][ks] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xs) << 4));
+        for (int a = 0; a < 8; ++a) {
+          const int r = wr * 128 + a * 16 + fr;
+          const int hp = r + 2 * (r >> lw) + Wd + 3 + tapoff;            // halo pixel of output pixel r for this tap
+          xf[a] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xs) << 4));
         }
-        if (s < 3 && more) {
-          constexpr int PP = (NWP + 2) / 3;
+        if (ks == 0 && more) {
 #pragma unroll
-          for (int q = 0; q < PP; ++q)
-            if (s * PP + q < NWP) issue_w(kt + 1, s * PP + q);
+          for (int q = 0; q < NWP; ++q) issue_w(kt + 1, q);
         }
-        // last strip: this wave's weight pieces of K-step kt + 1 have landed and its LDS reads of this stage (and, on tap 8, of the
+        // second half: this wave's weight pieces of K-step kt + 1 have landed and its LDS reads of this stage (and, on tap 8, of the
         // halo) have retired BEFORE the barrier behind which the other half reads the new stage / the halo is refilled
-        if (s == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (ks == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- MFMA section
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-              acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+          for (int jn = 0; jn < TN; ++jn)
+            acc[a][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[a], acc[a][jn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
       }
@@ -351,132 +346,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s, 0, fr, fq);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// The same ping-pong K loop for pointwise (1x1 / linear) layers with narrow outputs (N <= 1280: to_out, to_q, proj_in / proj_out,
-// ff.net.2 of the transformer blocks): 256 x 320 tiles, both operands streamed through two 64-deep stages (A 32 KB + W 40 KB per
-// K-step: 6.9 B per kFLOP against 13.8 for the 128 x 160 two-workgroup form), every A row read once.  Same-device micro-benchmark
-// (tools/micro/pingpong_gemm.hip): 320 x 320 at M = 262144 103 us vs 140 us, 640 x 640 62 vs 96, 1280 x 1280 50 vs 72, ff.net.2
-// 320 x 1280 232 vs 325 us.
-// ------------------------------------------------------------------------------------------------------------------------------------
 #ifdef DD_TRACE
-// debug build only (tools/pp_trace.py): per workgroup (entry, K loop start, K loop end, exit) in s_memrealtime ticks (10 ns) + HW_ID / XCC_ID
+// debug build only (tools/pp_trace.py): per tile (wait for the first K-step, K loop start, K loop end, end of the epilogue) in s_memrealtime ticks (10 ns)
 __device__ unsigned long long g_pp_trace[8192 * 6];
-#define PP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_pp_trace[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PP_STAMP(i) do { } while (0)
 #endif
-template <int TN>
-__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(ConvGemmParams p) {
-  constexpr int BM = 256, BN = 4 * TN * 16;
-  constexpr int BUF = (BM + BN) * 128;
-  constexpr int NP = 4 + TN;                           // pieces per wave and K-step: 4 of A, TN of W
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const bias_s = (float*)(smem + 2 * BUF);
-  float* const c1_s = bias_s + BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
-  PP_STAMP(0);
-#ifdef DD_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    g_pp_trace[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    g_pp_trace[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
-  }
-#endif
-  int tile;
-  {
-    const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-  const int KT = p.K >> 6;
-  if (tid < BN) {
-    bias_s[tid] = (p.flags & CF_BIAS) ? p.bias[n0 + tid] : 0.f;
-    c1_s[tid] = (p.flags & CF_LNFOLD) ? p.ln_c1[n0 + tid] : 0.f;
-  }
-  const int prow = lane >> 3, j = (lane & 7) ^ prow;
-  constexpr int TNP = TN & ~1;
-  const bf16_t* xt = p.x + (size_t)m0 * p.x_ld;          // per-tile base: 32-bit byte offsets only span 256 rows
-  unsigned aoff[4], woff[TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)((wave + 8 * i) * 8 + prow) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int R = (wave + 8 * i) * 8 + prow;
-    const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
-    const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
-    woff[i] = ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(j * 8)) * 2u;
-  }
-  auto issue = [&](int kt, int which) {
-    unsigned char* buf = smem + (kt & 1) * BUF;
-    const unsigned soff = (unsigned)kt * 128u;
-    if (which < 4) hdma16(xt, buf + (wave + 8 * which) * 1024, aoff[which], soff);
-    else hdma16(p.w, buf + BM * 128 + (wave + 8 * (which - 4)) * 1024, woff[which - 4], soff);
-  };
-  f32x4 acc[8][TN];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int q = 0; q < NP; ++q) issue(0, q);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  PP_STAMP(1);
-  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower row half runs one barrier behind
-  bf16x8 wf[TN][2], xf[2][2];
-  for (int kt = 0; kt < KT; ++kt) {
-    const unsigned char* Ab = smem + (kt & 1) * BUF;
-    const unsigned char* Bb = Ab + BM * 128;
-    const bool more = kt + 1 < KT;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s == 0) {
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int row = wc * (TN * 16) + jn * 16 + fr;
-            wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int row = wr * 128 + s * 32 + i * 16 + fr;
-          xf[i][ks] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-        }
-      if (s < 3 && more) {
-        constexpr int PP = (NP + 2) / 3;
-#pragma unroll
-        for (int q = 0; q < PP; ++q)
-          if (s * PP + q < NP) issue(kt + 1, s * PP + q);
-      }
-      if (s == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn)
-            acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_s_barrier();
-    }
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-  PP_STAMP(2);
-  auto m_of = [&](int r) { return m0 + r; };
-  pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, c1_s, (n0 / BN) * 4 + wc, fr, fq);
-  PP_STAMP(3);
-}
-
 // GEGLU epilogue of the persistent ping-pong GEMM (TN = 4: a wave owns two packed (16 hidden | 16 gate) groups).  The weight rows are
 // assigned to MFMA rows so that a lane holds, per 16-row tile, the hidden AND gate pre-activations of 8 consecutive output columns
 // (fq * 8 .. + 7 of the wave's 32): 16-byte stores of the product and of both halves of the CF_GEGLU_RAW stash.  bias / c1 in packed order.
@@ -604,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
   for (int q = 0; q < NP; ++q) issue(xt, wsoff, 0, 0, q);
   issue_aux(n0, 0);
   f32x4 acc[8][TN];
-  bf16x8 wf[TN][2], xf[2][2];
+  bf16x8 wf[TN], xf[8];
   for (int it = 0; it < count; ++it) {
     PPS_STAMP(tile, 0);
 #pragma unroll
@@ -632,31 +505,23 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
       const unsigned nw = more ? wsoff : wsoffn;
       const int nk = more ? kt + 1 : 0;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s == 0) {
+      for (int ks = 0; ks < 2; ++ks) {                  // two sections per K-step, one per K half (see conv_halo_kernel)
 #pragma unroll
-          for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              const int row = wc * (TN * 16) + jn * 16 + fr;
-              wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-            }
+        for (int jn = 0; jn < TN; ++jn) {
+          const int row = wc * (TN * 16) + jn * 16 + fr;
+          wf[jn] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int row = wr * 128 + s * 32 + i * 16 + fr;
-            xf[i][ks] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-          }
-        if (s < 3 && pre) {
-          constexpr int PP = (NP + 2) / 3;
-#pragma unroll
-          for (int q = 0; q < PP; ++q)
-            if (s * PP + q < NP) issue(nx, nw, nk, cur ^ 1, s * PP + q);
-          if (s == 2 && !more) issue_aux(n0n, (it + 1) & 1);
+        for (int a = 0; a < 8; ++a) {
+          const int row = wr * 128 + a * 16 + fr;
+          xf[a] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
         }
-        if (s == 3) {
+        if (ks == 0 && pre) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) issue(nx, nw, nk, cur ^ 1, q);
+          if (!more) issue_aux(n0n, (it + 1) & 1);
+        }
+        if (ks == 1) {
           if (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -664,12 +529,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-              acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+          for (int jn = 0; jn < TN; ++jn)
+            acc[a][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[a], acc[a][jn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
       }
@@ -720,19 +583,25 @@ int conv_halo_config(const ConvGemmParams& p) {
       p.K != 9 * p.cin) return 0;
   if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_GNFOLD)) || p.bias_sel) return 0;
   if ((p.flags & CF_GNFOLD) && (!p.gn_coef || p.shift)) return 0;
-  int tn = 0;
-  if (p.N % 320 == 0) tn = 5; else if (p.N % 256 == 0) tn = 4; else if (p.N == 128) tn = 2;
-  if (!tn) return 0;
-  const int bm = tn == 2 ? 512 : 256, bn = tn == 2 ? 128 : 64 * tn;
-  HaloGeo g;
-  if (!halo_geometry(p, bm, &g) || p.M != p.B * p.Ho * p.Wo) return 0;
+  // tile forms by preference: 512 x 160 / 512 x 128 (the halo-resident input is cheap, the streamed weights are not: 20 / 16 KB of
+  // weights + ~10 KB of halo per K-step instead of 40 / 32 + 5.6) where the image geometry allows 512-pixel tiles, else 256 x 320 / 256 x 256
+  static const int tall = getenv("DD_HALO_TALL") ? atoi(getenv("DD_HALO_TALL")) : 1;
   if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
   if ((size_t)p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;         // byte offsets are per image
-  if (p.ksplit > 1) return 0;
-  const int tiles = (p.M / bm) * (p.N / bn);
-  if (tiles < 192) return 0;                              // needs (most of) the chip: small grids keep the split-K forms
-  if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 512 + 64 > 163840) return 0;
-  return tn;
+  if (p.ksplit > 1 || p.M != p.B * p.Ho * p.Wo) return 0;
+  const int forms[4][3] = {{6, 512, 160}, {2, 512, 128}, {5, 256, 320}, {4, 256, 256}};
+  for (int f = 0; f < 4; ++f) {
+    const int tn = forms[f][0], bm = forms[f][1], bn = forms[f][2];
+    if (p.N % bn) continue;
+    if (bm == 512 && !tall && p.N != 128) continue;
+    if (tn == 2 && p.N % 320 == 0) continue;            // 320-multiples: 160-wide tiles
+    HaloGeo g;
+    if (!halo_geometry(p, bm, &g)) continue;
+    if ((p.M / bm) * (p.N / bn) < 192) continue;        // needs (most of) the chip: small grids keep the split-K forms
+    if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 512 + 64 > 163840) continue;
+    return tn;
+  }
+  return 0;
 }
 
 // pointwise ping-pong GEMM: 0 = not eligible, else TN (5: 256 x 320 tiles; 4: 256 x 256 tiles of a GEGLU projection)
@@ -745,7 +614,7 @@ int gemm_pp_config(const ConvGemmParams& p) {
   if ((p.M & 255) || p.K < 256 || p.ksplit > 1 || p.bias_sel || (p.x_ld & 7) || (p.y_ld & 7)) return 0;
   if ((size_t)256 * p.x_ld * 2 >= 0xF0000000ull || (size_t)p.N * p.K * 2 >= 0xF0000000ull) return 0;
   if (p.flags & CF_GEGLU) {
-    if (!geglu_on || on == 2) return 0;
+    if (!geglu_on) return 0;
     if (p.flags & ~(CF_BIAS | CF_GEGLU | CF_GEGLU_RAW | CF_LNFOLD)) return 0;
     if ((p.N & 255) || ((p.flags & CF_GEGLU_RAW) && (p.raw_ld & 7))) return 0;
     if ((p.M / 256) * (p.N / 256) < 192) return 0;
@@ -770,15 +639,7 @@ static hipError_t run_pps(const ConvGemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream) {
-  static const int mode = getenv("DD_GEMM_PP") ? atoi(getenv("DD_GEMM_PP")) : 1;
-  if (tn == 4) return run_pps<4, true>(p, stream);
-  if (mode != 2) return run_pps<5, false>(p, stream);
-  constexpr int BN = 320;                                // DD_GEMM_PP=2: the one-tile-per-workgroup form (A/B)
-  const int lds = 2 * (256 + BN) * 128 + 2 * BN * 4 + 64;
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)gemm_pp_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-  hipLaunchKernelGGL((gemm_pp_kernel<5>), dim3((p.M / 256) * (p.N / BN)), dim3(512), lds, stream, p);
-  return hipGetLastError();
+  return tn == 4 ? run_pps<4, true>(p, stream) : run_pps<5, false>(p, stream);
 }
 
 #ifdef DD_TRACE
@@ -789,6 +650,6 @@ extern "C" int dd_debug_read_pp_trace(unsigned long long* host, int n) {
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
   HaloGeo g;
-  if (!halo_geometry(p, tn == 2 ? 512 : 256, &g)) return hipErrorInvalidValue;
-  return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : run_halo<4, 2>(p, g, stream);
+  if (!halo_geometry(p, tn == 2 || tn == 6 ? 512 : 256, &g)) return hipErrorInvalidValue;
+  return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

@@ -33,7 +33,7 @@ def run(name, B, H, Cin, Cout, res=False, iters=6):
 
 
 tag = "halo=" + os.environ.get("DD_CONV_HALO", "1")
-out = [run("320>320@64", 64, 64, 320, 320, True), run("640>320@64", 64, 64, 640, 320), run("640>640@32", 64, 32, 640, 640, True),
+out = [run("960>320@64", 64, 64, 960, 320), run("320>320@64", 64, 64, 320, 320, True), run("640>320@64", 64, 64, 640, 320), run("640>640@32", 64, 32, 640, 640, True),
        run("1280>640@32", 64, 32, 1280, 640), run("1280>1280@16", 64, 16, 1280, 1280, True), run("2560>1280@16", 64, 16, 2560, 1280),
        run("512>512@64", 32, 64, 512, 512, True, 3), run("512>512@128", 32, 128, 512, 512, True, 2), run("256>256@256", 8, 256, 256, 256, True, 2), run("128>128@512", 8, 512, 128, 128, True, 2), run("256>128@512", 8, 512, 256, 128, False, 2)]
 print(tag, " | ".join(out))

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
     unsigned char* buf = smem + (kt & 1) * BUF;
     const unsigned soff = (unsigned)kt * 128u;
     // ablation (g_mode bit 4): the A operand is not re-loaded after K-tile 0 (what a halo slab would save for a 3x3 convolution: 8 of 9 taps)
+    // bit 5: no DMA at all after K-tile 1 (both stages stay what they are: the loop is MFMA + fragment reads + barriers only)
+    if ((amode & 32) && kt > 1) return;
     if (which < APC) { if (!(amode & 16) || kt == 0) dma16(A, buf + (wave + 8 * which) * 1024, aoff[which], soff); }
     else dma16(W, buf + BM * 128 + (wave + 8 * (which - APC)) * 1024, woff[which - APC], soff);
   };
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
 #pragma unroll
     for (int s = 0; s < 4; ++s) {             // 32-row strips of this wave's 128 rows
       // ---- load section (the SIMD partner is in its MFMA section)
-      if (s == 0) {
+      const bool rd = !(amode & 64) || kt == 0;             // bit 6: fragments are read in K-tile 0 only
+      if (s == 0 && rd) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
             wf[jn][ks] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
           }
       }
+      if (rd) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
           const int row = wr * 128 + s * 32 + i * 16 + fr;
           xf[i][ks] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
         }
+      }
       if (s < 3 && more) {
 #pragma unroll
         for (int q = 0; q < PP; ++q)
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // ---- MFMA section
       __builtin_amdgcn_s_setprio(1);
+      if (!(amode & 128)) {                                 // bit 7: no MFMAs
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -126,6 +132,115 @@ __global__ __launch_bounds__(512, 1) void pingpong_kernel(const bf16_t* A, const
 #pragma unroll
           for (int jn = 0; jn < TN; ++jn)
             acc[s * 2 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn][ks], xf[i][ks], acc[s * 2 + i][jn], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (!(amode & 256)) __builtin_amdgcn_s_barrier();     // bit 8: one barrier per strip (the halves are no longer phase-locked)
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two halves
+
+  // epilogue: a lane owns 4 consecutive output channels of one pixel per (row tile, column tile)
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int m = m0 + wr * 128 + a * 16 + fr;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int n = n0 + wc * (TN * 16) + jn * 16 + fq * 4;
+      uint2 o;
+      o.x = pack2bf(acc[a][jn][0], acc[a][jn][1]); o.y = pack2bf(acc[a][jn][2], acc[a][jn][3]);
+      *(uint2*)(C + (size_t)m * N + n) = o;
+    }
+  }
+}
+
+
+template <int TN>
+__global__ __launch_bounds__(512, 1) void pingpong2_kernel(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K) {
+  constexpr int BM = 256, BN = 4 * TN * 16;
+  constexpr int APC = BM / 8 / 8, BPC = BN / 8 / 8;       // 1 KB pieces per wave and K-tile: A 4, W TN
+  constexpr int BUF = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  // tile of this workgroup: n-tiles fastest inside one XCD
+  const int ntn = N / BN, tiles = (M / BM) * ntn;
+  const int per = tiles >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int ktiles = K >> 6;
+  const int amode = g_mode;
+
+  // DMA: wave w moves A pieces w, w + 8, ... and W pieces w, w + 8, ...; a lane's row inside its piece = lane >> 3, its 16-byte slot
+  // is swizzled on the source side
+  const int prow = lane >> 3, j = (lane & 7) ^ prow;
+  unsigned aoff[APC], woff[BPC];
+#pragma unroll
+  for (int i = 0; i < APC; ++i) aoff[i] = (unsigned)((m0 + (wave + 8 * i) * 8 + prow) * K + j * 8) * 2u;
+#pragma unroll
+  for (int i = 0; i < BPC; ++i) woff[i] = (unsigned)((n0 + (wave + 8 * i) * 8 + prow) * K + j * 8) * 2u;
+  auto issue = [&](int kt, int which) {       // piece `which` of this wave for K-tile kt
+    unsigned char* buf = smem + (kt & 1) * BUF;
+    const unsigned soff = (unsigned)kt * 128u;
+    // ablation (g_mode bit 4): the A operand is not re-loaded after K-tile 0 (what a halo slab would save for a 3x3 convolution: 8 of 9 taps)
+    // bit 5: no DMA at all after K-tile 1 (both stages stay what they are: the loop is MFMA + fragment reads + barriers only)
+    if ((amode & 32) && kt > 1) return;
+    if (which < APC) { if (!(amode & 16) || kt == 0) dma16(A, buf + (wave + 8 * which) * 1024, aoff[which], soff); }
+    else dma16(W, buf + BM * 128 + (wave + 8 * (which - APC)) * 1024, woff[which - APC], soff);
+  };
+  constexpr int NP = APC + BPC;               // pieces per wave and K-tile, issued in strips 0..2
+  constexpr int PP = (NP + 2) / 3;
+
+  f32x4 acc[8][TN];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: K-tile 0
+#pragma unroll
+  for (int q = 0; q < NP; ++q) issue(0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the lower row half runs one barrier behind
+
+  // two sections per K-tile, split by K half (ks): 8 x TN MFMAs between two barriers instead of 4 x TN x ... : half the barrier events
+  bf16x8 wf[TN], xf[8];
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const unsigned char* Ab = smem + (kt & 1) * BUF;
+    const unsigned char* Bb = Ab + BM * 128;
+    const bool more = kt + 1 < ktiles;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bool rd = !(amode & 64) || kt == 0;
+      if (rd) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int row = wc * (TN * 16) + jn * 16 + fr;
+          wf[jn] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int row = wr * 128 + a * 16 + fr;
+          xf[a] = *(const bf16x8*)(Ab + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+        }
+      }
+      if (ks == 0 && more) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue(kt + 1, q);
+      }
+      if (ks == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+      if (!(amode & 128)) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[a][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[a], acc[a][jn], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
     }
@@ -282,7 +397,7 @@ static int run(int M, int N, int K, int iters) {
   hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
   const int lds = (PC ? 3 : 2) * (256 + BN) * 128;
-  auto kern = PC ? prodcons_kernel : pingpong_kernel<TN>;
+  auto kern = PC ? prodcons_kernel : (getenv("PP2") ? pingpong2_kernel<TN> : pingpong_kernel<TN>);
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int tiles = (M / 256) * (N / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, dA, dW, dC, M, N, K);
@@ -316,7 +431,7 @@ int main(int argc, char** argv) {
   const int tn = argc > 4 ? atoi(argv[4]) : 5, iters = argc > 5 ? atoi(argv[5]) : 10;
   const int mode = argc > 6 ? atoi(argv[6]) : 0;
   hipMemcpyToSymbol(HIP_SYMBOL(g_mode), &mode, sizeof(int));
-  if (mode & 7) printf("[ablation mode %d: results are wrong on purpose] ", mode);
+  if (mode & ~8) printf("[ablation mode %d: results are wrong on purpose] ", mode);
   unsigned* dh; hipMalloc(&dh, 64); hipMemset(dh, 0, 64); hipMemcpyToSymbol(HIP_SYMBOL(g_hwid), &dh, sizeof(dh));
   atexit_ptr = dh;
   if (tn == 0) {
