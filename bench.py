@@ -296,7 +296,7 @@ def main():
         if prof is not None:
             cv = prof["conv_gemm"]
             ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + gemm_pp_kernel + conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + gemm_pps_kernel + conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": cv["ops"], "avg_launch_ms": cv["ms"] / max(cv["ops"], 1),
                                "algorithmic_flops_per_launch": cv["flops"] / max(cv["ops"], 1),

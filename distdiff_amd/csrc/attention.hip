@@ -13,6 +13,7 @@
 // inside a 32-deep step is the permutation key = 32c + 16*(j>>2) + 4*(lane>>4) + (j&3), which is exactly the
 // 4-row block order ds_read_b64_tr_b16 delivers. Row stride of the LDS tiles is 2*DPK+32 bytes:
 // bank-conflict free for both read kinds (tools/lds_conflicts.py).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -162,17 +163,21 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
     tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
     tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg, p.ldv, p.Nk, D, tid);
   }
+#ifndef DD_ATTN_ABL
+#define DD_ATTN_ABL 0          // timing ablations (results wrong): 1 no exp, 2 no barriers, 4 no row max, 8 no global prefetch after tile 0, 16 no LDS staging after tile 0
+#endif
   for (int k0 = 0; k0 < p.Nk; k0 += KT) {
-    __syncthreads();
-    if (PREFETCH) {
+    if (!(DD_ATTN_ABL & 2)) __syncthreads();
+    if ((DD_ATTN_ABL & 16) && k0 > 0) {
+    } else if (PREFETCH) {
       tile_store<KT, PREFETCH ? DPK : 32>(kreg, Ks, S, tid);
       tile_store<KT, PREFETCH ? DPK : 32>(vreg, Vs, S, tid);
     } else {
       stage_tile<KT, DPK>(Ks, S, kg + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, D, tid);
       stage_tile<KT, DPK, ONES>(Vs, S, vg + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, D, tid);
     }
-    __syncthreads();
-    if (PREFETCH && k0 + KT < p.Nk) {
+    if (!(DD_ATTN_ABL & 2)) __syncthreads();
+    if (PREFETCH && k0 + KT < p.Nk && !((DD_ATTN_ABL & 8) && k0 > 0)) {
       tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg + (size_t)(k0 + KT) * p.ldk, p.ldk, p.Nk - k0 - KT, D, tid);
       tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg + (size_t)(k0 + KT) * p.ldv, p.ldv, p.Nk - k0 - KT, D, tid);
     }
@@ -202,12 +207,14 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
             if (k0 + kt * 16 + 4 * g + r >= klim[qt]) st[qt][kt][r] = -INFINITY;
       }
       float mx = st[qt][0][0];
+      if (!(DD_ATTN_ABL & 4)) {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      }
       const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ps = 0.f;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
+          const float e = (DD_ATTN_ABL & 1) ? __builtin_fmaf(st[qt][kt][r], sl2, -mnew) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
           st[qt][kt][r] = e;
           if (!ONES) ps += e;
         }
@@ -263,6 +270,195 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
     }
     if (p.lse && g == 0 && (DSPLIT == 1 || wave == 0))
       p.lse[((size_t)b * p.H + h) * p.Nq + qrow[qt]] = (mrun[qt] + log2f(l)) * 0.6931471805599453f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, K/V tiles staged by LDS-DMA (buffer_load_dwordx4 ... lds) into a two-deep ring.  The register-staged form above spends a
+// quarter of its time on the staging itself (tools/_attn ablations, DESIGN.md 9.5: global load -> 16 VGPRs -> ds_write_b128, two
+// barriers per tile: d = 40 / 4096 keys 1520 us, 1165 us with the staging removed); here a tile is requested one tile ahead with three
+// DMA instructions per wave, lands in LDS without touching registers, and one barrier per tile is enough.
+// LDS rows are RG 16-byte granules: DG = D / 8 data granules, the rest padding that no DMA lane ever writes (the lanes of the pad
+// granules are masked off: an inactive lane leaves its 16-byte slot alone, tools/micro/buflds.hip) -- zeros for K, and for V the
+// 1.0 that makes P.V deliver the softmax row sums (ONES).  Row strides (96 B at d <= 40, 160 B at d = 64 / 80) are bank-conflict free for
+// the ds_read_b128 row fragments and the ds_read_b64_tr_b16 column fragments (tools/lds_conflicts.py).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adma16(const void* base, void* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffff00u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+template <int D>
+struct AttnDmaGeo {
+  static constexpr int DPK = (D + 31) / 32 * 32;
+  static constexpr int RB = D <= 40 ? 96 : D <= 80 ? 160 : DPK * 2 + 32;     // LDS row bytes (d = 64 / 80: no padding granule, or none past column 79: the over-read of the last K-step lands in the next row)
+  static constexpr int RG = RB / 16, DG = D / 8;             // granules per row, data granules
+};
+// NW waves per workgroup (4 or 8: eight waves share one K/V ring, half the DMA instructions per query; same waves per SIMD)
+template <int D, int QT, int KT, int NW>
+__global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(AttnParams p) {
+  using G = AttnDmaGeo<D>;
+  constexpr int DPK = G::DPK, KS = DPK / 32, DVT = (D + 15) / 16, S = G::RB, RG = G::RG, DG = G::DG;
+  constexpr int NKT = KT / 16, NC = KT / 32;
+  constexpr int QB = NW * QT * 16;
+  constexpr int TILE = KT * S;                               // bytes of one K (or V) tile
+  constexpr int NPM = KT * RG / 64;                          // DMA pieces (64 granules) per matrix and tile
+  constexpr int NPW = (2 * NPM + NW - 1) / NW;               // ... per wave (K pieces first, then V)
+  static_assert((KT * RG) % 64 == 0, "tile must be a whole number of 1 KB pieces");
+  constexpr bool ONES = (D % 16) != 0 && (D % 8) == 0;
+  constexpr unsigned OOR = 0xffffff00u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // [buf][K tile | V tile] + 128 B of zeros
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * QB + wave * QT * 16;
+
+  // ---- padding granules (and the tail behind the last row: the 64-wide K fragments / 16-wide V column tiles read past a row's end)
+  for (int r = tid; r < 2 * 2 * KT; r += NW * 64) {              // rows of both buffers, K and V alike
+    const bool isv = (r / KT) & 1;
+#pragma unroll
+    for (int v = DG; v < RG; ++v)
+      *(uint4*)(smem + r * S + v * 16) = make_uint4((ONES && isv && v == DG) ? 0x3f80u : 0u, 0, 0, 0);
+  }
+  if (tid < 8) *(uint4*)(smem + 4 * TILE + tid * 16) = make_uint4(0, 0, 0, 0);
+
+  bf16x8 qf[QT][KS];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + i16;
+    const bool valid = qrow[qt] < p.Nq;
+    load_row_frags<DPK>(qf[qt], p.q + ((size_t)b * p.Nq + (valid ? qrow[qt] : 0)) * p.ldq + h * D, valid, D, lane);
+  }
+  f32x4 o[QT][DVT];
+  float mrun[QT], lsum[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = -INFINITY; lsum[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+  const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+
+  // ---- this wave's DMA pieces: piece pc = wave + NW i (pc < NPM: K, else V); lane -> granule pc' * 64 + lane -> (row, granule in row)
+  unsigned voff[NPW];
+  int prow_[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pc = wave + NW * i, pm = pc < NPM ? pc : pc - NPM;
+    const int gi = pm * 64 + lane, row = gi / RG, v = gi - row * RG;
+    prow_[i] = v < DG ? row : -1;                            // -1: a padding granule (lane stays off)
+    voff[i] = ((unsigned)row * (unsigned)(pc < NPM ? p.ldk : p.ldv) + (unsigned)v * 8u) * 2u;
+  }
+  auto issue_tile = [&](int k0, int buf) {
+    const int nvalid = p.Nk - k0;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pc = wave + NW * i;
+      if (pc < 2 * NPM) {
+        const bool isv = pc >= NPM;
+        unsigned char* dst = smem + buf * 2 * TILE + (isv ? TILE : 0) + (isv ? pc - NPM : pc) * 1024;
+        if (prow_[i] >= 0)                                   // rows behind the last key are zero-filled by the range check
+          adma16(isv ? vg : kg, dst, prow_[i] < nvalid ? voff[i] : OOR, (unsigned)k0 * (unsigned)(isv ? p.ldv : p.ldk) * 2u);
+      }
+    }
+  };
+  issue_tile(0, 0);
+  int buf = 0;
+  for (int k0 = 0; k0 < p.Nk; k0 += KT, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the tile have landed ...
+    __syncthreads();                                         // ... everybody's have, and nobody still reads the other buffer
+    if (k0 + KT < p.Nk) issue_tile(k0 + KT, buf ^ 1);
+    const unsigned char* Ks = smem + buf * 2 * TILE;
+    const unsigned char* Vs = Ks + TILE;
+    f32x4 st[QT][NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
+      }
+    }
+    const bool partial = k0 + KT > p.Nk;                     // wave-uniform: only the last tile of a ragged key count needs masking
+    bf16x8 pf[QT][NC];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (partial) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + 4 * g + r >= p.Nk) st[qt][kt][r] = -INFINITY;
+      }
+      float mx = st[qt][0][0];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
+          st[qt][kt][r] = e;
+          if (!ONES) ps += e;
+        }
+      if (!ONES) lsum[qt] = lsum[qt] * alpha + ps;
+      mrun[qt] = mnew;
+      if (__any(alpha != 1.f)) {                              // wave-uniform: skip the O rescale when no row max moved
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) pf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 vf = lds_col_frag(Vs, 32 * c, S, dt, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], o[qt][dt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l;
+    if (ONES) {
+      l = __shfl(o[qt][DVT - 1][(D % 16) % 4], ((D % 16) / 4) * 16 + i16, 64);
+    } else {
+      l = lsum[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    if (qrow[qt] >= p.Nq) continue;
+    const float inv = 1.f / l;
+    bf16_t* op = p.o + ((size_t)b * p.Nq + qrow[qt]) * p.ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int dv = dt * 16 + 4 * g;
+      if (dv < D) {
+        uint2 u;
+        u.x = pack2bf(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+        u.y = pack2bf(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+        *(uint2*)(op + dv) = u;
+      }
+    }
+    if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.Nq + qrow[qt]] = (mrun[qt] + log2f(l)) * 0.6931471805599453f;
   }
 }
 
@@ -579,9 +775,26 @@ hipError_t run_fwd2(const AttnParams& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT, CAUSAL>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
 }
+template <int D, int QT, int KT, int NW>
+hipError_t run_fwd_dma(const AttnParams& p, hipStream_t s) {
+  constexpr int QB = NW * QT * 16;
+  constexpr size_t lds = 4 * KT * AttnDmaGeo<D>::RB + 128;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<D, QT, KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QT, KT, NW>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(NW * 64), lds, s, p);
+  return hipGetLastError();
+}
 // the causal mask (CLIP text encoder, forward only) is a template flag: the UNet / VAE loops carry no per-score mask code
 template <int D, int QT, int KT, int DSPLIT>
 hipError_t run_fwd(const AttnParams& p, hipStream_t s) {
+  static const int dma = getenv("DD_ATTN_DMA") ? atoi(getenv("DD_ATTN_DMA")) : 1;
+  // LDS-DMA staging: head dims whose rows are whole 16-byte granules, key / value row pitches within the 32-bit offset of one batch image
+  if constexpr (DSPLIT == 1 && D % 8 == 0 && D <= 80 && (KT * AttnDmaGeo<D>::RG) % 64 == 0) {   // d = 160: the two-deep ring would cost a workgroup per CU
+    if (dma && !p.causal && (size_t)p.Nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < 0xF0000000ull) {
+      if constexpr (D <= 40) { if (dma != 4 && p.Nq % (8 * QT * 16) == 0) return run_fwd_dma<D, QT, KT, 8>(p, s); }   // DD_ATTN_DMA=4: four-wave workgroups everywhere
+      return run_fwd_dma<D, QT, KT, 4>(p, s);
+    }
+  }
   return p.causal ? run_fwd2<D, QT, KT, DSPLIT, true>(p, s) : run_fwd2<D, QT, KT, DSPLIT, false>(p, s);
 }
 template <int D, int QT, int KT, int DSPLIT>

@@ -18,6 +18,20 @@ __global__ void k(const unsigned* src, unsigned* out, unsigned nbytes) {
   for (int i = 0; i < 4; ++i) out[lane * 4 + i] = lds[lane * 4 + i];
 }
 
+// EXEC-masked lanes: do they leave their 16-byte LDS slot alone, and do the active lanes still write at base + lane * 16?
+__global__ void kmask(const unsigned* src, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[64 * 4];
+  const int lane = threadIdx.x;
+  for (int i = 0; i < 4; ++i) lds[lane * 4 + i] = 0xdeadbeefu;
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0xffffff00, 0x00020000);
+  if (lane % 6 != 5)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, (unsigned)lane * 16u, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = 0; i < 4; ++i) out[lane * 4 + i] = lds[lane * 4 + i];
+}
+
 int main() {
   unsigned *src, *out;
   const unsigned n = 4096;   // dwords
@@ -29,5 +43,9 @@ int main() {
   unsigned o[256];
   hipMemcpy(o, out, 256 * 4, hipMemcpyDeviceToHost);
   for (int l : {0, 1, 2, 3, 60, 62, 63}) printf("lane %2d: %08x %08x %08x %08x\n", l, o[l * 4], o[l * 4 + 1], o[l * 4 + 2], o[l * 4 + 3]);
+  hipLaunchKernelGGL(kmask, dim3(1), dim3(64), 0, 0, src, out);
+  hipMemcpy(o, out, 256 * 4, hipMemcpyDeviceToHost);
+  printf("masked lanes (lane %% 6 == 5 inactive):\n");
+  for (int l : {0, 4, 5, 6, 11, 12, 63}) printf("lane %2d: %08x %08x %08x %08x\n", l, o[l * 4], o[l * 4 + 1], o[l * 4 + 2], o[l * 4 + 3]);
   return 0;
 }
