@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = (("conv_gemm_big_kernel", "conv_gemm_big_kernel"), ("conv_gemm_kernel", "conv_gemm_kernel"),
-            ("attn_fwd_kernel", "attn_fwd_kernel"), ("attn_bwd", "attn_bwd"), ("gn_", "gn_"),
+            ("attn_fwd_kernel", "attn_fwd"), ("attn_bwd", "attn_bwd"), ("gn_", "gn_"),
             ("ln_", "ln_"), ("conv_halo_kernel", "conv_halo_kernel"), ("gemm_pp_kernel", "gemm_pp"), ("splitk", "splitk"))
 
 
