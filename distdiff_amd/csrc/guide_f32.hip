@@ -15,6 +15,7 @@
 // Tile 64 x 64 x 16 per 256-thread workgroup, one 32x32 accumulator per wave, LDS K-major ([k][row], row stride 68 floats:
 // staging writes and fragment reads are both bank-conflict free), register-staged prefetch of the next K-step under the MFMAs.
 // The MFMA is issued swapped (A = weights, B = pixels) so a lane owns 4 consecutive output channels of one pixel (float4 epilogue).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -168,6 +169,57 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Params p) {
       for (int q = 0; q < 4; ++q)
         if (nb + q < p.N) yp[q] = h[q];
     }
+  }
+}
+
+// Narrow outputs (N <= 4: the input gradient of the guide's first convolution -- 3 image channels from 49 taps x 64 channels -- would fill
+// 3 of the 64 columns of an MFMA tile): one thread per output pixel, the weights of all N columns through the scalar cache, the SAME
+// k-ordered fmaf chain as the MFMA kernel.  A tap that the gather rejects (outside the image, wrong parity of a dilated gather)
+// contributes exact zeros there and is skipped here, so the results are bit-identical (tests/test_guide_f32_gpu.py).
+__global__ __launch_bounds__(256) void conv_f32_narrow_kernel(ConvF32Params p) {
+  const int tid = threadIdx.x;
+  const float* __restrict__ wsm = p.w;                // [N][K]: wave-uniform addresses -> scalar loads, the weights are SGPR operands of the fmas
+  const int m = blockIdx.x * 256 + tid;
+  if (m >= p.M) return;
+  const int HoWo = p.Ho * p.Wo;
+  const int b = m / HoWo, rem = m - b * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int pixb = b * p.H * p.W, iy0 = oy * p.stride, ix0 = ox * p.stride;
+  const int shift = p.shift, cin = p.cin, K = p.K, N = p.N;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < p.ntaps; ++tap) {
+    const int e = p.taptab[tap];
+    const int dx = (e & 63) - 32, dy = ((e >> 6) & 63) - 32;
+    const int ly = iy0 + dy, lx = ix0 + dx;
+    const int sy = ly >> shift, sx = lx >> shift;
+    bool ok = ly >= 0 && lx >= 0 && sy < p.H && sx < p.W;
+    if (p.parity) ok = ok && (((ly | lx) & 1) == 0);
+    if (!ok) continue;
+    const float* xp = p.x + (size_t)(pixb + sy * p.W + sx) * p.x_ld;
+    const float* wp = wsm + tap * cin;
+    for (int c = 0; c < cin; c += 4) {
+      const float4 xv = *(const float4*)(xp + c);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < N) {
+          const float4 wv = *(const float4*)(wp + n * K + c);
+          acc[n] = __builtin_fmaf(wv.x, xv.x, acc[n]);
+          acc[n] = __builtin_fmaf(wv.y, xv.y, acc[n]);
+          acc[n] = __builtin_fmaf(wv.z, xv.z, acc[n]);
+          acc[n] = __builtin_fmaf(wv.w, xv.w, acc[n]);
+        }
+      }
+    }
+  }
+  const int flags = p.flags;
+  for (int n = 0; n < N; ++n) {
+    float h = acc[n];
+    if (flags & CF_BIAS) h += p.bias[n];
+    if (flags & CF_RES) h += p.res[(size_t)m * p.res_ld + n];
+    if (flags & CF_RELU) h = fmaxf(h, 0.f);
+    if (flags & CF_RELU6) h = fminf(fmaxf(h, 0.f), 6.f);
+    if ((flags & CF_MASK) && !(p.mask[(size_t)m * p.mask_ld + n] > 0.f)) h = 0.f;
+    p.y[(size_t)m * p.y_ld + n] = h;
   }
 }
 
@@ -379,6 +431,11 @@ hipError_t launch_conv_f32(const ConvF32Params& p, hipStream_t s) {
   if (p.groups > 1 && ((p.cin & 15) || p.cpg_in < 1 || p.cpg_out < 1)) return hipErrorInvalidValue;
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0x7FFF0000ull) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  static const int narrow = getenv("DD_F32_NARROW") ? atoi(getenv("DD_F32_NARROW")) : 1;
+  if (narrow && p.N <= 4 && p.groups <= 1 && (size_t)p.N * p.K * 4 <= 65536 && p.M >= 4096) {
+    hipLaunchKernelGGL(conv_f32_narrow_kernel, dim3((p.M + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+  }
   const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64;
   hipLaunchKernelGGL(conv_f32_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
   return hipGetLastError();

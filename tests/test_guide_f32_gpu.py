@@ -45,6 +45,7 @@ def unrows(r, B, C, H, W):
 CASES = [
     # name, B, Cin, Cout, H, W, k, stride, pad, groups
     ("stem7x7", 2, 3, 64, 32, 32, 7, 2, 3, 1),
+    ("stem7x7_narrow_dgrad", 2, 3, 64, 96, 96, 7, 2, 3, 1),     # M = 18432 image pixels x 3 channels: the one-thread-per-pixel kernel
     ("1x1", 2, 64, 256, 14, 14, 1, 1, 0, 1),
     ("1x1_ragged", 1, 20, 36, 7, 5, 1, 1, 0, 1),
     ("3x3", 2, 64, 64, 14, 14, 3, 1, 1, 1),
