@@ -91,6 +91,11 @@ __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* g, bool 
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef DD_ATTN_ABL
+// timing ablations (results wrong): 1 no exp, 2 no barriers, 4 no row max, 8 / 16 no global prefetch / LDS staging after tile 0 (register-
+// staged kernel), 32 no LDS fragment reads after tile 0, 64 no P.V MFMAs, 128 no DMA after tile 0 (LDS-DMA kernel)
+#define DD_ATTN_ABL 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward.  grid (ceil(Nq / QB), H, B), 256 threads. DSPLIT=1: each wave owns QT 16-query tiles;
@@ -163,9 +168,6 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
     tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
     tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg, p.ldv, p.Nk, D, tid);
   }
-#ifndef DD_ATTN_ABL
-#define DD_ATTN_ABL 0          // timing ablations (results wrong): 1 no exp, 2 no barriers, 4 no row max, 8 no global prefetch after tile 0, 16 no LDS staging after tile 0
-#endif
   for (int k0 = 0; k0 < p.Nk; k0 += KT) {
     if (!(DD_ATTN_ABL & 2)) __syncthreads();
     if ((DD_ATTN_ABL & 16) && k0 > 0) {
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
   int buf = 0;
   for (int k0 = 0; k0 < p.Nk; k0 += KT, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the tile have landed ...
-    __syncthreads();                                         // ... everybody's have, and nobody still reads the other buffer
-    if (k0 + KT < p.Nk) issue_tile(k0 + KT, buf ^ 1);
+    if (!(DD_ATTN_ABL & 2) || k0 == 0) __syncthreads();      // ... everybody's have, and nobody still reads the other buffer
+    if (k0 + KT < p.Nk && !((DD_ATTN_ABL & 128) && k0 > 0)) issue_tile(k0 + KT, buf ^ 1);
     const unsigned char* Ks = smem + buf * 2 * TILE;
     const unsigned char* Vs = Ks + TILE;
     f32x4 st[QT][NKT];
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       for (int qt = 0; qt < QT; ++qt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
+        const bf16x8 kf = ((DD_ATTN_ABL & 32) && k0 > 0) ? qf[0][ks] : lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
       }
@@ -400,12 +402,14 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
             if (k0 + kt * 16 + 4 * g + r >= p.Nk) st[qt][kt][r] = -INFINITY;
       }
       float mx = st[qt][0][0];
+      if (!(DD_ATTN_ABL & 4)) {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      }
       const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ps = 0.f;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
+          const float e = (DD_ATTN_ABL & 1) ? __builtin_fmaf(st[qt][kt][r], sl2, -mnew) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -mnew));
           st[qt][kt][r] = e;
           if (!ONES) ps += e;
         }
@@ -430,7 +434,8 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const bf16x8 vf = lds_col_frag(Vs, 32 * c, S, dt, lane);
+        const bf16x8 vf = ((DD_ATTN_ABL & 32) && k0 > 0) ? qf[0][0] : lds_col_frag(Vs, 32 * c, S, dt, lane);
+        if (DD_ATTN_ABL & 64) { if (dt == 0 && c == 0) o[0][0][0] += pf[0][0][0] + pf[QT - 1][NC - 1][3]; continue; }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], o[qt][dt], 0, 0, 0);
       }
