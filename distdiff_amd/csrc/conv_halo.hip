@@ -285,7 +285,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
       // every read of the previous chunk's halo has retired (both groups waited lgkmcnt(0) in front of their last X barrier)
       if (grp == 0) {
         if (gnf) load_coef(c);
+#ifndef DD_HALO_ABL       // timing ablation (-DDD_HALO_ABL: results wrong): the halo of chunk 0 serves every chunk -- what the refill at a chunk boundary costs
         issue_halo(c);
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else if (gnf) {
         // group 1 arrives here one barrier late, i.e. behind the barrier in front of which group 0 waited for the new halo: it applies
