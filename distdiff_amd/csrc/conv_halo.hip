@@ -39,9 +39,10 @@ __device__ __forceinline__ float hrow16_sum(float v) {
 // stores) and 4 of an odd last tile.  bias / residual / ReLU / CF_STATS (GroupNorm partials per 64-row block) as in conv_gemm2.hip, plus
 // CF_LNFOLD (out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n]: the LayerNorm in front of this linear is folded into its weights) and
 // CF_ROWSTATS ((sum, sum^2) of every output row over this wave's TN * 16 columns, for the LayerNorm that consumes the tensor).
+// stats_s: the (mean, rstd) rows of the tile in LDS (persistent GEMM: they arrive with the bias through the LDS-DMA ring), or null (global loads).
 template <int TN, class MOf>
 __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc)[8][TN], MOf m_of, int wr, int wc, int n0,
-                                            const float* bias_s, const float* c1_s, int span, int fr, int fq) {
+                                            const float* bias_s, const float* c1_s, int span, int fr, int fq, const float* stats_s = nullptr) {
   constexpr int TNP = TN & ~1;
   const int fl = p.flags;
   const int wb = n0 + wc * (TN * 16);
@@ -75,7 +76,8 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
         for (int t = 0; t < TN / 2; ++t) rvp[a4][t] = make_uint4(0, 0, 0, 0);
         rvo[a4] = make_uint2(0, 0);
       }
-      lst[a4] = (fl & CF_LNFOLD) ? *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2) : make_float2(0.f, 1.f);
+      lst[a4] = !(fl & CF_LNFOLD) ? make_float2(0.f, 1.f)
+                : stats_s ? *(const float2*)(stats_s + (wr * 128 + (blk * 4 + hb * 2 + a4) * 16 + fr) * 2) : *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2);
     }
 #pragma unroll
     for (int a4 = 0; a4 < 2; ++a4) {
@@ -357,7 +359,7 @@ __device__ unsigned long long g_pp_trace[8192 * 6];
 // (fq * 8 .. + 7 of the wave's 32): 16-byte stores of the product and of both halves of the CF_GEGLU_RAW stash.  bias / c1 in packed order.
 template <class MOf>
 __device__ __forceinline__ void pp_epilogue_geglu(const ConvGemmParams& p, f32x4 (&acc)[8][4], MOf m_of, int wr, int wc, int n0,
-                                                  const float* bias_s, const float* c1_s, int fr, int fq) {
+                                                  const float* bias_s, const float* c1_s, int fr, int fq, const float* stats_s) {
   const int fl = p.flags;
   const int pk = wc * 64 + (fq >> 1) * 32 + (fq & 1) * 8;      // packed column (inside the tile) of this lane's first hidden value
   float4 bh[2], bg[2], ch[2], cg[2];
@@ -374,7 +376,7 @@ __device__ __forceinline__ void pp_epilogue_geglu(const ConvGemmParams& p, f32x4
 #pragma unroll
     for (int a4 = 0; a4 < 2; ++a4) {
       mrow[a4] = m_of(wr * 128 + (a2 + a4) * 16 + fr);
-      lst[a4] = (fl & CF_LNFOLD) ? *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2) : make_float2(0.f, 1.f);
+      lst[a4] = (fl & CF_LNFOLD) ? *(const float2*)(stats_s + (wr * 128 + (a2 + a4) * 16 + fr) * 2) : make_float2(0.f, 1.f);
     }
 #pragma unroll
     for (int a4 = 0; a4 < 2; ++a4) {
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
   constexpr int BM = 256, BN = 4 * TN * 16;
   constexpr int BUF = (BM + BN) * 128;
   constexpr int NP = 4 + TN;                           // pieces per wave and K-step: 4 of A, TN of W
-  constexpr int AUX = 2 * BUF;                         // [slot][bias 2 KB | c1 2 KB]
+  constexpr int AUX = 2 * BUF;                         // [slot][bias 2 KB | c1 2 KB | (mean, rstd) of the tile's 256 rows 2 KB]
+  constexpr int SLOT = 6144;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -467,8 +470,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
     if (which < 4) hdma16(xt, b + (wave + 8 * which) * 1024, aoff[which], (unsigned)kt * 128u);
     else hdma16(p.w, b + BM * 128 + (wave + 8 * (which - 4)) * 1024, woff[which - 4], wsoff + (unsigned)kt * 128u);
   };
-  auto issue_aux = [&](int n0, int slot) {
-    if (wave < 4) hdma16(auxbase ? (const void*)auxbase : (const void*)p.w, smem + AUX + slot * 4096 + (wave >> 1) * 2048 + (wave & 1) * 1024, auxoff, (unsigned)n0 * 4u);
+  const unsigned statoff = (p.flags & CF_LNFOLD) ? (unsigned)((wave & 1) * 1024 + lane * 16) : 0xffffff00u;    // waves 4, 5: 128 rows x 8 B each
+  auto issue_aux = [&](int m0, int n0, int slot) {
+    if (wave < 4) hdma16(auxbase ? (const void*)auxbase : (const void*)p.w, smem + AUX + slot * SLOT + (wave >> 1) * 2048 + (wave & 1) * 1024, auxoff, (unsigned)n0 * 4u);
+    else if (wave < 6) hdma16(p.ln_stats ? (const void*)(p.ln_stats + (size_t)m0 * 2) : (const void*)p.w, smem + AUX + slot * SLOT + 4096 + (wave & 1) * 1024, statoff, 0u);
   };
   int tile = first;
   int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
   int cur = 0;
 #pragma unroll
   for (int q = 0; q < NP; ++q) issue(xt, wsoff, 0, 0, q);
-  issue_aux(n0, 0);
+  issue_aux(m0, n0, 0);
   f32x4 acc[8][TN];
   bf16x8 wf[TN], xf[8];
   for (int it = 0; it < count; ++it) {
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
         if (ks == 0 && pre) {
 #pragma unroll
           for (int q = 0; q < NP; ++q) issue(nx, nw, nk, cur ^ 1, q);
-          if (!more) issue_aux(n0n, (it + 1) & 1);
+          if (!more) issue_aux(m0n, n0n, (it + 1) & 1);
         }
         if (ks == 1) {
           if (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -542,11 +547,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     PPS_STAMP(tile, 2);
-    const float* bias_s = (const float*)(smem + AUX + (it & 1) * 4096);
+    const float* bias_s = (const float*)(smem + AUX + (it & 1) * SLOT);
     const int m0c = m0;
     auto m_of = [&](int r) { return m0c + r; };
-    if constexpr (GEGLU) pp_epilogue_geglu(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, fr, fq);
-    else pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, (n0 / BN) * 4 + wc, fr, fq);
+    if constexpr (GEGLU) pp_epilogue_geglu(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, fr, fq, bias_s + 1024);
+    else pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s + 512, (n0 / BN) * 4 + wc, fr, fq, bias_s + 1024);
     PPS_STAMP(tile, 3);
     tile = tile_n; m0 = m0n; n0 = n0n; xt = xtn; wsoff = wsoffn;
   }
@@ -631,7 +636,7 @@ int gemm_pp_config(const ConvGemmParams& p) {
 template <int TN, bool GEGLU>
 static hipError_t run_pps(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * TN;
-  const int lds = 2 * (256 + BN) * 128 + 2 * 4096;
+  const int lds = 2 * (256 + BN) * 128 + 2 * 6144;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)gemm_pps_kernel<TN, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   static const int cus = [] { int d = 0, n = 256; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 8 ? n & ~7 : 8; }();
