@@ -1,5 +1,6 @@
 """CPU tests of the drop-in CLI host logic (SURVEY.md section 8c pin 5): flags/defaults, shard ranges, output paths,
 skip-if-exists resume and the per-image call sequence, against a recording fake engine (no GPU)."""
+import pytest
 import os
 
 import torch
@@ -98,6 +99,27 @@ def test_prototype_builder_known_answer():
         got = sorted(map(tuple, np.round(l[c] / (c + 1) / 5).astype(int).tolist()))
         assert got == [(0, 0, 1), (0, 1, 0), (1, 0, 0)]
         assert np.allclose(g[c], feats[np.array(tg) == c].mean(0))
+
+
+def test_average_linkage_labels_match_sklearn():
+    """The prototype builder's own clustering against the call the reference makes (dataloader.py:704-717: sklearn
+    AgglomerativeClustering(n_clusters=K, linkage='average')): identical labels, including their numbering, on unit-norm features."""
+    import numpy as np
+    cluster = pytest.importorskip("sklearn.cluster")
+    from distdiff_amd.prototypes import average_linkage_labels
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        n, d = int(rng.integers(3, 100)), int(rng.integers(2, 48))
+        K = int(rng.integers(1, min(n, 6) + 1))
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        if trial % 3 == 0:
+            X[n // 2:] += 0.5
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        ref = cluster.AgglomerativeClustering(n_clusters=K, linkage="average").fit(X).labels_
+        assert np.array_equal(average_linkage_labels(X, K), ref), (n, d, K)
+    assert average_linkage_labels(np.zeros((1, 4), np.float32), 1).tolist() == [0]
+    with pytest.raises(ValueError):
+        average_linkage_labels(np.zeros((2, 4), np.float32), 3)
 
 
 def test_image_transform_matches_reference_pipeline(tmp_path):
