@@ -472,8 +472,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
   const int D = p.D;
   const size_t total = (size_t)p.B * p.H * p.Nq;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int q = (int)(idx % p.Nq);
-    const int h = (int)((idx / p.Nq) % p.H);
+    // heads fastest: neighbouring threads read neighbouring D-wide segments of one token row (the rows are [token][head][d])
+    const int h = (int)(idx % p.H);
+    const int q = (int)((idx / p.H) % p.Nq);
     const int b = (int)(idx / ((size_t)p.Nq * p.H));
     const bf16_t* op = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
     const bf16_t* dp = p.d_o + ((size_t)b * p.Nq + q) * p.lddo + h * D;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += a[e] * c[e];
     }
-    p.delta[idx] = s;
+    p.delta[((size_t)b * p.H + h) * p.Nq + q] = s;
   }
 }
 

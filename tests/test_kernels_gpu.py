@@ -74,6 +74,9 @@ CONV_CASES = [
     ("halo_w256_2x128_tiles", 1, 64, 256, 256, 256, 3, 1, 1, 0),  # images wider than 128: 2 x 128-pixel tiles
     ("halo_w512_up2", 1, 64, 256, 64, 256, 3, 1, 1, 1),           # logical 128 x 512
     ("halo_n128_512x128_tiles", 1, 128, 128, 256, 512, 3, 1, 1, 0),  # N = 128: 512-row tiles (4 x 128 pixels), waves 4 x 2
+    # N <= 4 (conv_out of the decoder 128 -> 3 and of the UNet 320 -> 4): the small kernel's 256 x 64 tiles
+    ("n3_vae_conv_out", 1, 128, 3, 256, 256, 3, 1, 1, 0),
+    ("n4_unet_conv_out", 16, 320, 4, 64, 64, 3, 1, 1, 0),
 ]
 
 
