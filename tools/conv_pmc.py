@@ -18,5 +18,6 @@ def run(B, H, Cin, Cout, k, iters=6):
     torch.cuda.synchronize()
 
 
-run(32, 64, 320, 320, 3)      # 128x160 tiles, two 4-wave workgroups per CU, 45 K-steps per item
-run(32, 16, 1280, 1280, 3)    # 256x160 tiles, one 8-wave workgroup per CU, 180 K-steps per item
+B = int(os.environ.get("PMC_B", "64"))   # the bench's CFG batch
+run(B, 64, 320, 320, 3)      # round 2: 128x160 tiles, two 4-wave workgroups per CU, 45 K-steps per item; round 3: halo kernel, 512x160 tiles
+run(B, 16, 1280, 1280, 3)    # round 2: 256x160 tiles, one 8-wave workgroup per CU, 180 K-steps per item; round 3: halo kernel, 256x320 tiles

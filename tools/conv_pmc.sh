@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / TCP counters of the persistent conv kernel on two deep 3x3 shapes: bash tools/conv_pmc.sh -> gpurun_out/conv_pmc.txt
+# SQ / TCP counters of the conv kernels (round 3: the halo-resident ping-pong kernel) on two deep 3x3 shapes: bash tools/conv_pmc.sh -> gpurun_out/conv_pmc.txt
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/conv_pmc
@@ -21,8 +21,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "conv_gemm_big_kernel" not in n: continue
-        key = "2wg 128x160" if "<2, 2, 4, 5, 2" in n else "8-wave 256x160" if "<4, 2, 4, 5, 3" in n else n[:60]
+        if "conv_gemm_big_kernel" not in n and "conv_halo_kernel" not in n: continue
+        key = "2wg 128x160" if "<2, 2, 4, 5, 2" in n else "8-wave 256x160" if "<4, 2, 4, 5, 3" in n else "halo 512x160" if "conv_halo_kernel<5, 2>" in n else "halo 256x320" if "conv_halo_kernel<5, 4>" in n else n[:60]
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[key][r["Counter_Name"]] += 1
 with open(root + "/../conv_pmc.txt", "w") as out:
     for k in acc:

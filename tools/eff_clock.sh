@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/effclk
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/run -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_profile > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/run -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_profile $EFFCLK_ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd $ROOT
 ls $OUT/run/* | head
 python3 - <<'PY'
@@ -20,7 +20,7 @@ for r in rows:
         continue
     dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     n = r["Kernel_Name"]
-    f = "conv" if "conv_gemm" in n else "attn" if "attn" in n else "norm" if ("gn_" in n or "ln_" in n) else "other"
+    f = "conv_halo" if "conv_halo" in n else "gemm_pps" if "gemm_pps" in n else "conv_old" if "conv_gemm" in n else "attn" if "attn" in n else "norm" if ("gn_" in n or "ln_" in n) else "other"
     fam[f][0] += float(r["Counter_Value"]); fam[f][1] += dur; fam[f][2] += 1
 for f, (cyc, ns, k) in fam.items():
     print("%-6s %6d launches  %.1f ms  GRBM_GUI_ACTIVE/ns = %.3f (x8 XCDs if summed: %.3f GHz per XCD)" % (f, k, ns / 1e6, cyc / ns, cyc / ns / 8))
