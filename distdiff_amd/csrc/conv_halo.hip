@@ -8,11 +8,13 @@
 //     rows) plus a one-pixel border -- (R + 2) x (W + 2) pixels x 128 B -- are staged ONCE per chunk, zero-filled outside the image by
 //     the buffer load's range check, and the A fragments of tap (dy, dx) are read at pixel + dy * (W + 2) + dx.  Input traffic per
 //     K-step falls from 32 KB to ~5.6 KB; only the weights stream every K-step;
-//   * 256 x 320 (or 256 x 256) tiles, 8 waves as 2 (M) x 4 (N), wave tile 128 x 80: 40 KB of weights per 10.5 MFLOP K-step;
-//   * the two waves of a SIMD (row halves wr = 0 / 1) run the same program one s_barrier apart: between two barriers one issues the
-//     4 * TN MFMAs of a 32-row strip while the other reads fragments and issues its share of the next K-step's weight DMA
+//   * 512 x 160 / 512 x 128 / 256 x 320 / 256 x 256 tiles, 8 waves as 4 x 2 or 2 x 4, wave tile 128 x 80 (64): 20-40 KB of weights per
+//     10.5 MFLOP K-step;
+//   * the two waves of a SIMD (different row groups) run the same program one s_barrier apart: between two barriers one issues the
+//     8 * TN MFMAs of a K half while the other reads fragments and issues its share of the next K-step's weight DMA
 //     (cdna_hip_programming.md section 5, "The 256^2 8-phase template"; MI355X_MICROARCH.md "Two waves per SIMD").
-// Not persistent: one workgroup per tile, XCD-aware tile order (n-tiles fastest inside an XCD).
+// The 3x3 kernel is not persistent (one workgroup per tile, XCD-aware tile order, n-tiles fastest inside an XCD: a persistent form
+// measured slower); the pointwise GEMM of the same loop (gemm_pps_kernel, below) is.
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
