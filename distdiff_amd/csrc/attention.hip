@@ -34,6 +34,10 @@ __device__ __forceinline__ bf16x8 lds_col_frag(const unsigned char* base, int r0
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
+// v_max_f32 / v_max3_f32 as single instructions: fmaxf() on MFMA results makes the compiler put a canonicalising v_max_f32 v, v, v in
+// front (5 of the 16 max instructions per query tile and KV tile in the ISA of the forward kernel, which is bound by the vector issue port)
+__device__ __forceinline__ float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   uint4 u;
   u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
@@ -403,14 +407,17 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       }
       float mx = st[qt][0][0];
       if (!(DD_ATTN_ABL & 4)) {
+        mx = vmax3(mx, st[qt][0][1], st[qt][0][2]);
+        mx = vmax2(mx, st[qt][0][3]);
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int kt = 1; kt < NKT; ++kt) {
+          mx = vmax3(mx, st[qt][kt][0], st[qt][kt][1]);
+          mx = vmax3(mx, st[qt][kt][2], st[qt][kt][3]);
+        }
+        mx = vmax2(mx, __shfl_xor(mx, 16, 64));
+        mx = vmax2(mx, __shfl_xor(mx, 32, 64));
       }
-      const float mnew = fmaxf(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
+      const float mnew = vmax2(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ps = 0.f;
 #pragma unroll
