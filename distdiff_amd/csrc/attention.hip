@@ -302,7 +302,11 @@ struct AttnDmaGeo {
   static constexpr int RG = RB / 16, DG = D / 8;             // granules per row, data granules
 };
 // NW waves per workgroup (4 or 8: eight waves share one K/V ring, half the DMA instructions per query; same waves per SIMD)
-template <int D, int QT, int KT, int NW>
+// LZ ("lazy reference"): the scores leave the QK^T MFMAs as log2-domain differences to a per-row reference -- Q carries scale * log2(e),
+// the first MFMA of every score chain starts from -reference instead of 0 -- so p = exp2(score) needs no fma, and the reference only
+// moves when a tile's maximum exceeds it by more than 2^LZ_SLACK (exact in floating point: the reference cancels in O / l; a tile far
+// above it is rebased before its exponentials).  The row maximum is still computed, but nothing waits for it.
+template <int D, int QT, int KT, int NW, bool LZ>
 __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(AttnParams p) {
   using G = AttnDmaGeo<D>;
   constexpr int DPK = G::DPK, KS = DPK / 32, DVT = (D + 15) / 16, S = G::RB, RG = G::RG, DG = G::DG;
@@ -338,6 +342,17 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     qrow[qt] = qbase + qt * 16 + i16;
     const bool valid = qrow[qt] < p.Nq;
     load_row_frags<DPK>(qf[qt], p.q + ((size_t)b * p.Nq + (valid ? qrow[qt] : 0)) * p.ldq + h * D, valid, D, lane);
+    if (LZ && !p.q_prescaled) {                            // Q not prescaled by the producer: fold scale * log2(e) in here (one more bf16 rounding)
+      const float c = p.scale * LOG2E;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float f[8];
+        unpack8(__builtin_bit_cast(uint4, qf[qt][ks]), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= c;
+        qf[qt][ks] = __builtin_bit_cast(bf16x8, pack8(f));
+      }
+    }
   }
   f32x4 o[QT][DVT];
   float mrun[QT], lsum[QT];
@@ -348,6 +363,9 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     for (int dt = 0; dt < DVT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float sl2 = p.scale * LOG2E;
+  f32x4 negm[QT];                                           // LZ: -reference of this lane's query row, the start value of its score chains
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) negm[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
   const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
 
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < QT; ++qt) st[qt][kt] = LZ ? negm[qt] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = ((DD_ATTN_ABL & 32) && k0 > 0) ? qf[0][ks] : lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
@@ -417,6 +435,35 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
         mx = vmax2(mx, __shfl_xor(mx, 16, 64));
         mx = vmax2(mx, __shfl_xor(mx, 32, 64));
       }
+      if constexpr (LZ) {
+        // mx = this tile's row maximum relative to the reference (the scores already are).  First tile (reference 0: plain scores) or
+        // a tile more than 2^LZ_SLACK above the reference: rebase by mx before the exponentials; wave-uniform, rare after the first tile
+        constexpr float LZ_SLACK = 24.f;
+        if (k0 == 0 || __any(mx > LZ_SLACK)) {
+          const float d = k0 == 0 ? mx : fmaxf(mx, 0.f);     // new reference = old + d
+          const float alpha = k0 == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[qt][kt][r] -= d;
+#pragma unroll
+          for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
+          if (!ONES) lsum[qt] *= alpha;
+          mrun[qt] = (k0 == 0 ? 0.f : mrun[qt]) + d;
+          const float nm = -mrun[qt];
+          negm[qt] = f32x4{nm, nm, nm, nm};
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[qt][kt][r]);
+            st[qt][kt][r] = e;
+            if (!ONES) ps += e;
+          }
+        if (!ONES) lsum[qt] += ps;
+      } else {
       const float mnew = vmax2(mrun[qt], mx * sl2);           // running max in the scaled log2 domain (sl2 > 0)
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ps = 0.f;
@@ -433,6 +480,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       if (__any(alpha != 1.f)) {                              // wave-uniform: skip the O rescale when no row max moved
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
+      }
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) pf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
@@ -788,14 +836,19 @@ hipError_t run_fwd2(const AttnParams& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT, CAUSAL>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
 }
-template <int D, int QT, int KT, int NW>
-hipError_t run_fwd_dma(const AttnParams& p, hipStream_t s) {
+template <int D, int QT, int KT, int NW, bool LZ>
+hipError_t run_fwd_dma2(const AttnParams& p, hipStream_t s) {
   constexpr int QB = NW * QT * 16;
   constexpr size_t lds = 4 * KT * AttnDmaGeo<D>::RB + 128;
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<D, QT, KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QT, KT, NW>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(NW * 64), lds, s, p);
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<D, QT, KT, NW, LZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QT, KT, NW, LZ>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
+}
+template <int D, int QT, int KT, int NW>
+hipError_t run_fwd_dma(const AttnParams& p, hipStream_t s) {
+  static const int lazy = getenv("DD_ATTN_LAZY") ? atoi(getenv("DD_ATTN_LAZY")) : 0;
+  return (lazy || p.q_prescaled) ? run_fwd_dma2<D, QT, KT, NW, true>(p, s) : run_fwd_dma2<D, QT, KT, NW, false>(p, s);
 }
 // the causal mask (CLIP text encoder, forward only) is a template flag: the UNet / VAE loops carry no per-score mask code
 template <int D, int QT, int KT, int DSPLIT>

@@ -198,7 +198,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
           p.k = act_ptr(c, P.t[op.k]); p.v = act_ptr(c, P.t[op.v]); p.ldk = P.t[op.k].ld; p.ldv = P.t[op.v].ld;
         }
         p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
-        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
+        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = op.q_prescaled ? 0.6931471805599453f : 1.f / sqrtf((float)op.D); p.q_prescaled = op.q_prescaled;
         p.causal = op.causal;
         if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 0) <= c.tmp_cap)
           HIPCHK(launch_attention_gemm_fwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
@@ -332,7 +332,7 @@ void run_bwd(const Program& P, const Ctx& c) {
         }
         p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
         p.delta = p.lse + (size_t)q.B * op.heads * op.Nq;
-        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = 1.f / sqrtf((float)op.D);
+        p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = op.q_prescaled ? 0.6931471805599453f : 1.f / sqrtf((float)op.D); p.q_prescaled = op.q_prescaled;
         p.d_o = grad_ptr(c, y); p.lddo = y.ld; p.dq = grad_ptr(c, q); p.lddq = q.ld;
         if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 1) <= c.tmp_cap)
           HIPCHK(launch_attention_gemm_bwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));

@@ -82,11 +82,11 @@ struct Builder {
     return y;
   }
   // self attention: q,k,v are views ; cross attention: k,v come from slot (constant, no grad)
-  int attn(int q, int k, int v, int heads, int Nq, int Nk, int cross_slot, int causal = 0) {
+  int attn(int q, int k, int v, int heads, int Nq, int Nk, int cross_slot, int causal = 0, int q_prescaled = 0) {
     const Tn& tq = P.t[q];
     int y = P.tensor(tq.B, tq.H, tq.W, tq.C);
     Op op; op.kind = OP_ATTN; op.q = q; op.k = k; op.v = v; op.y = y; op.heads = heads; op.D = tq.C / heads; op.Nq = Nq; op.Nk = Nk;
-    op.cross_slot = cross_slot; op.causal = causal;
+    op.cross_slot = cross_slot; op.causal = causal; op.q_prescaled = q_prescaled;
     // wide heads (AutoencoderKL mid block) run through GEMMs on a materialised score matrix: per-image scratch (attention_gemm.hip)
     if (op.D >= 256 && cross_slot < 0 && !causal)
       P.scratch_tmp = std::max(P.scratch_tmp, attention_gemm_workspace(Nq, Nk, op.D, P.want_grad ? 1 : 0));
@@ -359,15 +359,19 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     // self attention (fused QKV projection, no bias)
     // the three LayerNorms of a block are folded into the linear each of them feeds (Builder::fold_ln; DD_NO_LN_FOLD=1 builds the plain graph)
     const bool fold = ln_fold_enabled();
+    // the softmax scale 1/sqrt(d) * log2(e) lives in the to_q rows: the attention forward exponentiates the MFMA results as they are
+    const int qs = attn_prescale() ? 1 : 0;
+    const float qscale = qs ? 1.4426950408889634f / sqrtf((float)(C / heads)) : 1.f;
     int n = b.ln(h, make_norm(E, m, t + ".norm1"), 1e-5f);
-    int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false, fold ? t + ".norm1" : ""));
+    int qkv = b.conv(n, make_conv_cat(E, m, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, false, fold ? t + ".norm1" : "",
+                                      qs ? C : 0, qscale));
     if (fold) b.fold_ln();
     int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
-    int a = b.attn(q, k, v, heads, HW, HW, -1);
+    int a = b.attn(q, k, v, heads, HW, HW, -1, 0, qs);
     h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
     // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
     n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
-    int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false, fold ? t + ".norm2" : ""));
+    int q2 = b.conv(n, make_conv(E, m, t + ".attn2.to_q", 0, false, false, fold ? t + ".norm2" : "", qs ? C : 0, qscale));
     if (fold) b.fold_ln();
     if (P.t[q2].B == E->cfg.max_batch && b.full_batch == 2 * E->cfg.max_batch) {
       // Up to here the unconditional and the conditional half of the CFG batch were the SAME computation (same latents, same timestep;
@@ -381,7 +385,7 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     slot.wv = make_conv(E, m, t + ".attn2.to_v", 0, false, false);
     slot.C = C;
     E->cross_slots.push_back(slot);
-    a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1);
+    a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1, 0, qs);
     h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
     // GEGLU feed-forward
     n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);

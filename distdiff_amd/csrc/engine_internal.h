@@ -97,6 +97,7 @@ struct Op {
   int G = 0, silu = 0; float eps = 0;
   int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
   int causal = 0, act_kind = 0;
+  int q_prescaled = 0;         // OP_ATTN: the to_q weights carry 1/sqrt(D) * log2(e) (attn_prescale(); the kernels then get scale = ln 2)
   int patch = 0, sel_stride = 0;   // OP_PATCHIFY: patch size; OP_SELECT: row stride (tokens per image)
   size_t stats_off = 0;  // fp32 stats / lse in the activation slab
   bool fused = false;    // OP_CONCAT: both operands live inside the output buffer (column views): no copy, forward or backward
@@ -344,11 +345,16 @@ inline int guide_feat_dim(const dd_config& c) { return guide_feat_dim_decl(c); }
 namespace ddi {
 // engine_weights.cpp
 ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, int Cin, int KH, int KW, int pad, int groups, bool need_bwd);
+// qrows / qscale: output rows [0, qrows) (weights and bias, forward and input-gradient packings) are multiplied by qscale before the bf16
+// rounding -- the attention query projection carrying 1/sqrt(D) * log2(e) (attn_prescale)
 ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_bias, int Cout, int Cin, int KH, int KW, int pad, bool geglu,
-                     bool need_bwd, bool fold = false, const float* ln_gamma = nullptr, const float* ln_beta = nullptr);
+                     bool need_bwd, bool fold = false, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, int qrows = 0,
+                     float qscale = 1.f);
 ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& prefix, int pad, bool geglu = false, bool has_bias = true,
-                 const std::string& ln = "");
-ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias, const std::string& ln = "");
+                 const std::string& ln = "", int qrows = 0, float qscale = 1.f);
+ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias, const std::string& ln = "",
+                     int qrows = 0, float qscale = 1.f);
+bool attn_prescale();       // fold the softmax scale into the to_q weights of the UNet's transformer blocks (DD_ATTN_PRESCALE=0: off)
 ConvW* make_conv_bn(dd_engine* E, const std::string& model, const std::string& conv, const std::string& bn, int pad, float eps, int cin_total);
 NormW* make_norm(dd_engine* E, const std::string& model, const std::string& prefix);
 bool ln_fold_enabled();

@@ -39,8 +39,24 @@ ConvW* make_conv_f32(dd_engine* E, const float* w, const float* bias, int Cout, 
 // (kernels.h CF_LNFOLD): the FORWARD packing holds gamma o W, the bias W beta + b, ln_c1 the column sums of the bf16-rounded folded
 // weights (the rank-1 correction must cancel what the MFMAs actually accumulate); the input-gradient packing keeps the plain W, the
 // LayerNorm's own backward multiplies by gamma as before.
-ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_bias, int Cout, int Cin, int KH, int KW, int pad,
-                     bool geglu, bool need_bwd, bool fold, const float* ln_gamma, const float* ln_beta) {
+ConvW* make_conv_raw(dd_engine* E, const float* w_in, const float* bias_in, bool has_bias, int Cout, int Cin, int KH, int KW, int pad,
+                     bool geglu, bool need_bwd, bool fold, const float* ln_gamma, const float* ln_beta, int qrows, float qscale) {
+  // the softmax scale of an attention query projection, folded into its rows (both packings: the attention backward returns the
+  // gradient with respect to the SCALED query)
+  std::vector<float> wq, bq;
+  const float* w = w_in;
+  const float* bias = bias_in;
+  if (qrows > 0 && qscale != 1.f && !E->shape_only) {
+    const size_t per = (size_t)Cin * KH * KW;
+    wq.assign(w_in, w_in + (size_t)Cout * per);
+    for (size_t i = 0; i < (size_t)qrows * per; ++i) wq[i] *= qscale;
+    w = wq.data();
+    if (bias_in) {
+      bq.assign(bias_in, bias_in + Cout);
+      for (int n = 0; n < qrows; ++n) bq[n] *= qscale;
+      bias = bq.data();
+    }
+  }
   auto cw = std::make_unique<ConvW>();
   cw->Cout = Cout; cw->Cin = Cin; cw->KH = KH; cw->KW = KW; cw->pad = pad; cw->geglu = geglu;
   if (fold && (KH != 1 || KW != 1)) throw std::runtime_error("LayerNorm folding needs a linear layer");
@@ -87,9 +103,11 @@ ConvW* make_conv_raw(dd_engine* E, const float* w, const float* bias, bool has_b
 }
 
 bool ln_fold_enabled() { static const bool on = !getenv("DD_NO_LN_FOLD"); return on; }
+bool attn_prescale() { static const bool on = !(getenv("DD_ATTN_PRESCALE") && atoi(getenv("DD_ATTN_PRESCALE")) == 0); return on; }
 
 // ln: prefix of the LayerNorm to fold into this linear ("" = none)
-ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& prefix, int pad, bool geglu, bool has_bias, const std::string& ln) {
+ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& prefix, int pad, bool geglu, bool has_bias, const std::string& ln,
+                 int qrows, float qscale) {
   const HostTensor& w = E->get(model, prefix + ".weight");
   const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
   const int KH = w.shape.size() == 4 ? (int)w.shape[2] : 1, KW = w.shape.size() == 4 ? (int)w.shape[3] : 1;
@@ -97,12 +115,13 @@ ConvW* make_conv(dd_engine* E, const std::string& model, const std::string& pref
   const float* b = hb ? E->get(model, prefix + ".bias").data.data() : nullptr;
   const bool fold = !ln.empty();
   return make_conv_raw(E, w.data.data(), b, hb, Cout, Cin, KH, KW, pad, geglu, E->cfg.enable_grad != 0, fold,
-                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr);
+                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr,
+                       qrows, qscale);
 }
 
 // several linears sharing the input, concatenated along Cout (fused QKV)
 ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<std::string>& prefixes, bool with_bias,
-                     const std::string& ln) {
+                     const std::string& ln, int qrows, float qscale) {
   std::vector<float> w, b;
   int Cin = 0, Cout = 0;
   for (auto& p : prefixes) {
@@ -114,7 +133,8 @@ ConvW* make_conv_cat(dd_engine* E, const std::string& model, const std::vector<s
   }
   const bool fold = !ln.empty();
   return make_conv_raw(E, w.data(), with_bias ? b.data() : nullptr, with_bias, Cout, Cin, 1, 1, 0, false, E->cfg.enable_grad != 0, fold,
-                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr);
+                       fold ? E->get(model, ln + ".weight").data.data() : nullptr, fold ? E->get(model, ln + ".bias").data.data() : nullptr,
+                       qrows, qscale);
 }
 
 // conv (no bias) followed by eval-mode BatchNorm, folded: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)

@@ -137,7 +137,7 @@ struct AttnParams {
   bf16_t* dq; bf16_t* dk; bf16_t* dv;       // dk/dv may be null (cross attention: dQ only)
   int lddq, lddk, lddv;
   float* delta;                             // [B][H][Nq] scratch: rowsum(dO*O)
-  int accumulate_dq;                        // unused for now (dq is written)
+  int q_prescaled;                          // Q already carries 1/sqrt(D) * log2(e) (folded into the to_q weights): scores are log2-domain; pass scale = ln 2
   int causal;                               // forward only: key j visible to query i iff j <= i (CLIP text encoder)
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);

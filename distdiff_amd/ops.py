@@ -256,8 +256,9 @@ def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None):
     return o, lse, dq, dk, dv
 
 
-def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False):
-    """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors)."""
+def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False, q_prescaled=False):
+    """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors).  q_prescaled: q already carries
+    1/sqrt(D) * log2(e) (the engine folds it into the to_q weights); pass scale = ln 2 then."""
     L = _lib.lib()
     p = AttnParams()
     o = torch.zeros((B * Nq, H * D), device=q.device, dtype=torch.bfloat16)
@@ -266,6 +267,7 @@ def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=F
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     p.B, p.H, p.Nq, p.Nk, p.D, p.scale = B, H, Nq, Nk, D, scale
     p.causal = 1 if causal else 0
+    p.q_prescaled = 1 if q_prescaled else 0
     check(L.dd_op_attention_fwd(C.byref(p), _stream()), "attn_fwd")
     if d_o is None:
         return o, lse

@@ -378,6 +378,48 @@ def test_attention(ops, case):
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
 
 
+PRE_CASES = [("self_d40", 2, 8, 512, 512, 40, 1.0), ("self_d40_peaky", 1, 8, 1024, 2048, 40, 2.0), ("cross77_d40", 2, 8, 256, 77, 40, 1.0),
+             ("self_d64", 1, 2, 200, 200, 64, 1.5), ("self_d80", 1, 4, 256, 320, 80, 1.5), ("self_d160", 1, 2, 64, 64, 160, 1.0)]
+
+
+@pytest.mark.parametrize("case", PRE_CASES, ids=[c[0] for c in PRE_CASES])
+def test_attention_with_prescaled_query(ops, case):
+    """q_prescaled (AttnParams): the engine folds 1/sqrt(d) * log2(e) into the to_q weights, so the query tensor the kernels see is
+    q' = c q and the scores q'.k are log2-domain; the forward (lazy-reference LDS-DMA kernel at d <= 80, the register-staged kernel at
+    d = 160) and the backward get scale = ln 2.  Reference: softmax(ln 2 * q'.k) on the same bf16 q'.  Peaky case: scores of sigma 4
+    plus a drift along the keys (tiles far above the first tile's reference are rebased)."""
+    name, B, H, Nq, Nk, D, amp = case
+    g = torch.Generator().manual_seed(11)
+    c = math.log2(math.e) / math.sqrt(D)
+    q = torch.randn(B, Nq, H, D, generator=g) * amp
+    k = torch.randn(B, Nk, H, D, generator=g) * amp
+    if amp > 1.9:
+        u = torch.randn(H, D, generator=g)
+        u = u / u.norm(dim=-1, keepdim=True)
+        a = math.sqrt(12.0 * math.sqrt(D))
+        q = q + a * u
+        k = k + (torch.linspace(0, 1, Nk)[None, :, None, None] * a) * u
+    qp, k = bf(q * c), bf(k)
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    ln2 = math.log(2.0)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qp, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * ln2
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr)
+    d_o = bf(torch.randn(B, Nq, H, D, generator=g))
+    gq, gk, gv = torch.autograd.grad(ref, (qr, kr, vr), d_o)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    cross = Nk == 77
+    o, lse, dq, dk, dv = ops.attention(dev(qp, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, ln2, d_o=dev(d_o, Nq), need_dkv=not cross,
+                                       q_prescaled=True)
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref.detach(), rtol=2e-2, atol=2e-3, what=name + " O")
+    assert_close(lse, torch.logsumexp(s.detach(), dim=-1), rtol=1e-3, atol=2e-3, what=name + " LSE")
+    assert_close(dq.reshape(B, Nq, H, D), gq, rtol=3e-2, atol=3e-3, what=name + " dQ")
+    if not cross:
+        assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what=name + " dK")
+        assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
+
+
 @pytest.mark.parametrize("D,H", [(40, 8), (80, 8)])
 def test_attention_4096_keys_peaky_logits(ops, D, H):
     """The UNet's 64x64 self-attention (4096 queries x 4096 keys, d = 40; d = 80 at 32x32 uses the same kernel) with PEAKY logits:
