@@ -549,7 +549,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 // backward dQ: same streaming structure as the forward (keys/values through LDS).
 //   dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T dS^T
 // ------------------------------------------------------------------------------------------------
-template <int D, int QT, int KT, int DSPLIT>
+// PS: the query is prescaled (AttnParams::q_prescaled: scale * log2(e) == 1).  Either way the row constants are the INITIAL accumulators
+// of the two score chains -- S starts from -lse (in units of the raw score), dP from -delta -- so p = exp2(S [* scale log2 e]) and dS = p * dP
+// need no subtraction per score (cdna_hip_programming.md, attention backward: "Row constants as the initial accumulator").
+template <int D, int QT, int KT, int DSPLIT, bool PS>
 __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
@@ -591,6 +594,17 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
   const bf16_t* kg = p.k + (size_t)b * p.Nk * p.ldk + h * D;
   const bf16_t* vg = p.v + (size_t)b * p.Nk * p.ldv + h * D;
 
+  // initial accumulators of the score chains (per query row = per lane: the row sits on the MFMA column)
+  f32x4 sinit[QT], dinit[QT];
+  {
+    const float isl2 = PS ? 1.f : 1.f / sl2;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float a = -lse2[qt] * isl2, d = -delta[qt];
+      sinit[qt] = f32x4{a, a, a, a};
+      dinit[qt] = f32x4{d, d, d, d};
+    }
+  }
   // K/V tiles are register-staged one tile ahead like the forward (the global latency hides under the previous tile's MFMAs)
   constexpr bool PREFETCH = (DPK <= 160);
   TileRegs<KT, PREFETCH ? DPK : 32> kreg, vreg;
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) { st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int qt = 0; qt < QT; ++qt) { st[qt][kt] = sinit[qt]; dpt[qt][kt] = dinit[qt]; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 kf = lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
@@ -639,9 +653,9 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
           for (int r = 0; r < 4; ++r) {
             const int key = k0 + kt * 16 + 4 * g + r;
             // keys beyond Nk only exist in the last tile of a ragged key count (wave-uniform test: no per-score select otherwise)
-            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sl2, -lse2[qt]));
+            float pr = __builtin_amdgcn_exp2f(PS ? st[qt][kt][r] : st[qt][kt][r] * sl2);
             if (ragged && key >= p.Nk) pr = 0.f;
-            st[qt][kt][r] = pr * (dpt[qt][kt][r] - delta[qt]);
+            st[qt][kt][r] = pr * dpt[qt][kt][r];
           }
 #pragma unroll
         for (int c = 0; c < NC; ++c) dsf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
 //   S = Q K^T ; P = exp(S*scale - LSE) ; dP = dO V^T ; dS = P o (dP - delta)
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ------------------------------------------------------------------------------------------------
-template <int D, int KTW, int QTL, int DSPLIT>
+template <int D, int KTW, int QTL, int DSPLIT, bool PS>
 __global__ __launch_bounds__(256, DD_AW_DKV(D)) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int DPK = (D + 31) / 32 * 32;
   constexpr int KS = DPK / 32;
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(256, DD_AW_DKV(D)) void attn_bwd_dkv_kernel(AttnPar
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;
   unsigned char* Os = smem + QTL * S;
-  float* ls = (float*)(smem + 2 * QTL * S);   // [QTL] lse*log2e, then [QTL] delta
+  float* ls = (float*)(smem + 2 * QTL * S);   // [QTL] -lse (in raw-score units), then [QTL] -delta: the initial accumulators of S and dP
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -722,12 +736,12 @@ __global__ __launch_bounds__(256, DD_AW_DKV(D)) void attn_bwd_dkv_kernel(AttnPar
   // Q / dO tiles (and their lse / delta rows) are register-staged one tile ahead for the small head dims
   constexpr bool PREFETCH = (DPK <= 160);
   TileRegs<QTL, PREFETCH ? DPK : 32> qreg, oreg;
-  float lreg = INFINITY, dreg = 0.f;
+  float lreg = -INFINITY, dreg = 0.f;
   auto load_rows = [&](int q0) {
     if (tid < QTL) {
       const bool v = q0 + tid < p.Nq;
-      lreg = v ? lseg[q0 + tid] * LOG2E : INFINITY;      // +inf -> P = 0 for padded query rows
-      dreg = v ? delg[q0 + tid] : 0.f;
+      lreg = v ? -lseg[q0 + tid] * (PS ? LOG2E : LOG2E / sl2) : -INFINITY;      // -inf -> P = 0 for padded query rows
+      dreg = v ? -delg[q0 + tid] : 0.f;
     }
   };
   if (PREFETCH) {
@@ -757,31 +771,29 @@ __global__ __launch_bounds__(256, DD_AW_DKV(D)) void attn_bwd_dkv_kernel(AttnPar
       f32x4 s[KTW][NQT], dp[KTW][NQT];
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
-        // the first K slice accumulates onto a literal zero (an inline-constant C operand: no v_mov zeroing of 16 accumulators)
+        // the first K slice accumulates onto the row constants of its four query rows: -lse for S, -delta for dP
+        const f32x4 sin4 = *(const f32x4*)(ls + qt * 16 + 4 * g), din4 = *(const f32x4*)(ls + QTL + qt * 16 + 4 * g);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 qfr = lds_row_frag(Qs, qt * 16 + i16, S, g + 4 * ks);
           const bf16x8 ofr = lds_row_frag(Os, qt * 16 + i16, S, g + 4 * ks);
 #pragma unroll
           for (int kt = 0; kt < KTW; ++kt) {
-            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[kt][qt], 0, 0, 0);
-            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : dp[kt][qt], 0, 0, 0);
+            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], ks == 0 ? sin4 : s[kt][qt], 0, 0, 0);
+            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kt][ks], ks == 0 ? din4 : dp[kt][qt], 0, 0, 0);
           }
         }
       }
       // s[kt][qt][r] = S[q = q0 + qt*16 + 4g + r][key = krow[kt]]
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
-        float l2[4], de[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { l2[r] = ls[qt * 16 + 4 * g + r]; de[r] = ls[QTL + qt * 16 + 4 * g + r]; }
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(s[kt][qt][r] * sl2 - l2[r]);
+            const float pr = __builtin_amdgcn_exp2f(PS ? s[kt][qt][r] : s[kt][qt][r] * sl2);
             s[kt][qt][r] = pr;
-            dp[kt][qt][r] = pr * (dp[kt][qt][r] - de[r]);
+            dp[kt][qt][r] = pr * dp[kt][qt][r];
           }
       }
 #pragma unroll
@@ -863,25 +875,33 @@ hipError_t run_fwd(const AttnParams& p, hipStream_t s) {
   }
   return p.causal ? run_fwd2<D, QT, KT, DSPLIT, true>(p, s) : run_fwd2<D, QT, KT, DSPLIT, false>(p, s);
 }
-template <int D, int QT, int KT, int DSPLIT>
-hipError_t run_dq(const AttnParams& p, hipStream_t s) {
+template <int D, int QT, int KT, int DSPLIT, bool PS>
+hipError_t run_dq2(const AttnParams& p, hipStream_t s) {
   constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
   constexpr int QB = (DSPLIT == 1 ? 4 : 1) * QT * 16;
   constexpr size_t lds = 2 * KT * S;
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, QT, KT, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, QT, KT, DSPLIT>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
+  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, QT, KT, DSPLIT, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, QT, KT, DSPLIT, PS>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
 }
-template <int D, int KTW, int QTL, int DSPLIT>
-hipError_t run_dkv(const AttnParams& p, hipStream_t s) {
+template <int D, int QT, int KT, int DSPLIT>
+hipError_t run_dq(const AttnParams& p, hipStream_t s) {
+  return p.q_prescaled ? run_dq2<D, QT, KT, DSPLIT, true>(p, s) : run_dq2<D, QT, KT, DSPLIT, false>(p, s);
+}
+template <int D, int KTW, int QTL, int DSPLIT, bool PS>
+hipError_t run_dkv2(const AttnParams& p, hipStream_t s) {
   constexpr int DPK = (D + 31) / 32 * 32, S = DPK * 2 + 32;
   constexpr int KB = (DSPLIT == 1 ? 4 : 1) * KTW * 16;
   constexpr size_t lds = 2 * QTL * S + 2 * QTL * sizeof(float);
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT>), dim3((p.Nk + KB - 1) / KB, p.H, p.B), dim3(256), lds, s, p);
+  if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, KTW, QTL, DSPLIT, PS>), dim3((p.Nk + KB - 1) / KB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
+}
+template <int D, int KTW, int QTL, int DSPLIT>
+hipError_t run_dkv(const AttnParams& p, hipStream_t s) {
+  return p.q_prescaled ? run_dkv2<D, KTW, QTL, DSPLIT, true>(p, s) : run_dkv2<D, KTW, QTL, DSPLIT, false>(p, s);
 }
 
 }  // namespace
