@@ -14,6 +14,7 @@
 // 4-row block order ds_read_b64_tr_b16 delivers. Row stride of the LDS tiles is 2*DPK+32 bytes:
 // bank-conflict free for both read kinds (tools/lds_conflicts.py).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -110,6 +111,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 // (tools/bench_attn_occ.py, same device: d = 40 forward 1612 -> 1527 us at 4 waves / 128 VGPRs with 7 spilled registers; d = 80
 // 397 -> 327 us at 3 waves / 168 VGPRs, its 77-key cross-attention 91 -> 82 us; NOT for d = 64 at 4 waves (48 spills: 1190 -> 1910 us),
 // d = 40 at 5 waves (3x slower) or the backward kernels at 3 waves (d = 40: 1620 -> 1680 us)).
+#ifndef DD_ATTN_SAFE_ONLY
+#define DD_ATTN_SAFE_ONLY 0      // 1: the lazy forward always takes the per-tile row maximum (A/B builds; results identical up to rounding)
+#endif
 #ifndef DD_AW_FWD
 #define DD_AW_FWD(D) ((D) <= 40 ? 4 : (D) <= 80 ? 3 : 1)
 #endif
@@ -172,7 +176,10 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
     tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
     tile_load<KT, PREFETCH ? DPK : 32, ONES>(vreg, vg, p.ldv, p.Nk, D, tid);
   }
-  for (int k0 = 0; k0 < p.Nk; k0 += KT) {
+  // the tile body is instantiated twice: PARTIAL (ragged last tile / causal mask) is compile-time, so the full tiles carry none of the
+  // mask's compares and index arithmetic (as a run-time test the compiler hoisted them in front of the branch)
+  auto tile = [&](auto partial_c, int k0) {
+    constexpr bool partial = decltype(partial_c)::value;
     if (!(DD_ATTN_ABL & 2)) __syncthreads();
     if ((DD_ATTN_ABL & 16) && k0 > 0) {
     } else if (PREFETCH) {
@@ -199,13 +206,11 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
         for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
       }
     }
-    // wave-uniform: only the last tile of a ragged key count (or a causal mask, CLIP text encoder) needs masking
-    const bool partial = k0 + KT > p.Nk || CAUSAL;
     bf16x8 pf[QT][NC];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       // softmax is VALU-bound at d = 40 (one exp per score): keep it to max + fma + exp + add per element
-      if (partial) {
+      if constexpr (partial) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -249,6 +254,12 @@ __global__ __launch_bounds__(256, DD_AW_FWD(D)) void attn_fwd_kernel(AttnParams 
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], o[qt][dt], 0, 0, 0);
       }
+  };
+  {
+    int k0 = 0;
+    if constexpr (!CAUSAL)
+      for (; k0 + KT <= p.Nk; k0 += KT) tile(std::false_type{}, k0);
+    for (; k0 < p.Nk; k0 += KT) tile(std::true_type{}, k0);
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -392,12 +403,14 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       }
     }
   };
-  issue_tile(0, 0);
-  int buf = 0;
-  for (int k0 = 0; k0 < p.Nk; k0 += KT, buf ^= 1) {
+  // One K/V tile.  FIRST / PARTIAL / SAFE are compile-time so that the steady-state instance carries none of the ragged-tile mask
+  // arithmetic (the compiler hoisted its 33 compares / index adds in front of the branch when it was a run-time test: a sixth of the
+  // vector instructions of a kernel that is bound by the vector issue port) and, for the lazy form, no row maximum at all.
+  auto tile = [&](auto first_c, auto partial_c, auto safe_c, int k0, int buf) {
+    constexpr bool FIRST = decltype(first_c)::value, PARTIAL = decltype(partial_c)::value, SAFE = decltype(safe_c)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the tile have landed ...
-    if (!(DD_ATTN_ABL & 2) || k0 == 0) __syncthreads();      // ... everybody's have, and nobody still reads the other buffer
-    if (k0 + KT < p.Nk && !((DD_ATTN_ABL & 128) && k0 > 0)) issue_tile(k0 + KT, buf ^ 1);
+    if (!(DD_ATTN_ABL & 2) || FIRST) __syncthreads();        // ... everybody's have, and nobody still reads the other buffer
+    if (!PARTIAL && k0 + KT < p.Nk && !((DD_ATTN_ABL & 128) && !FIRST)) issue_tile(k0 + KT, buf ^ 1);
     const unsigned char* Ks = smem + buf * 2 * TILE;
     const unsigned char* Vs = Ks + TILE;
     f32x4 st[QT][NKT];
@@ -407,16 +420,15 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       for (int qt = 0; qt < QT; ++qt) st[qt][kt] = LZ ? negm[qt] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = ((DD_ATTN_ABL & 32) && k0 > 0) ? qf[0][ks] : lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
+        const bf16x8 kf = ((DD_ATTN_ABL & 32) && !FIRST) ? qf[0][ks] : lds_row_frag(Ks, kt * 16 + i16, S, g + 4 * ks);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kt], 0, 0, 0);
       }
     }
-    const bool partial = k0 + KT > p.Nk;                     // wave-uniform: only the last tile of a ragged key count needs masking
     bf16x8 pf[QT][NC];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      if (partial) {
+      if constexpr (PARTIAL) {                               // only the last tile of a ragged key count needs masking
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
             if (k0 + kt * 16 + 4 * g + r >= p.Nk) st[qt][kt][r] = -INFINITY;
       }
       float mx = st[qt][0][0];
-      if (!(DD_ATTN_ABL & 4)) {
+      if (!(DD_ATTN_ABL & 4) && (!LZ || FIRST || SAFE)) {
         mx = vmax3(mx, st[qt][0][1], st[qt][0][2]);
         mx = vmax2(mx, st[qt][0][3]);
 #pragma unroll
@@ -436,20 +448,26 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
         mx = vmax2(mx, __shfl_xor(mx, 32, 64));
       }
       if constexpr (LZ) {
-        // mx = this tile's row maximum relative to the reference (the scores already are).  First tile (reference 0: plain scores) or
-        // a tile more than 2^LZ_SLACK above the reference: rebase by mx before the exponentials; wave-uniform, rare after the first tile
+        // The scores already are differences to the row's reference.  First tile (reference 0: plain scores): the reference becomes
+        // the tile's row maximum.  Later tiles: the optimistic pass (SAFE = false) exponentiates them as they are -- no row maximum,
+        // nothing to wait for -- and the row sums tell at the end whether a row ran away from its reference (see the tail of the
+        // kernel); the safe pass rebases a tile more than 2^LZ_SLACK above the reference before its exponentials (wave-uniform, rare).
         constexpr float LZ_SLACK = 24.f;
-        if (k0 == 0 || __any(mx > LZ_SLACK)) {
-          const float d = k0 == 0 ? mx : fmaxf(mx, 0.f);     // new reference = old + d
-          const float alpha = k0 == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);
+        bool rebase = FIRST;
+        if constexpr (!FIRST && SAFE) rebase = __any(mx > LZ_SLACK);
+        if (rebase) {
+          const float d = FIRST ? mx : fmaxf(mx, 0.f);       // new reference = old + d
+          const float alpha = FIRST ? 1.f : __builtin_amdgcn_exp2f(-d);
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[qt][kt][r] -= d;
+          if constexpr (!FIRST) {
 #pragma unroll
-          for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
-          if (!ONES) lsum[qt] *= alpha;
-          mrun[qt] = (k0 == 0 ? 0.f : mrun[qt]) + d;
+            for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
+            if (!ONES) lsum[qt] *= alpha;
+          }
+          mrun[qt] = (FIRST ? 0.f : mrun[qt]) + d;
           const float nm = -mrun[qt];
           negm[qt] = f32x4{nm, nm, nm, nm};
         }
@@ -489,11 +507,56 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const bf16x8 vf = ((DD_ATTN_ABL & 32) && k0 > 0) ? qf[0][0] : lds_col_frag(Vs, 32 * c, S, dt, lane);
+        const bf16x8 vf = ((DD_ATTN_ABL & 32) && !FIRST) ? qf[0][0] : lds_col_frag(Vs, 32 * c, S, dt, lane);
         if (DD_ATTN_ABL & 64) { if (dt == 0 && c == 0) o[0][0][0] += pf[0][0][0] + pf[QT - 1][NC - 1][3]; continue; }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], o[qt][dt], 0, 0, 0);
       }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  // the whole key loop: tile 0, the full tiles, the ragged last tile
+  auto sweep = [&](auto safe_c) {
+    issue_tile(0, 0);
+    const int nfull = p.Nk / KT;                             // tiles without masking
+    if (nfull == 0) { tile(T_{}, T_{}, safe_c, 0, 0); return; }
+    tile(T_{}, F_{}, safe_c, 0, 0);
+    int buf = 1, k0 = KT;
+    for (; k0 < nfull * KT; k0 += KT, buf ^= 1) tile(F_{}, F_{}, safe_c, k0, buf);
+    if (k0 < p.Nk) tile(F_{}, T_{}, safe_c, k0, buf);
+  };
+  if constexpr (LZ) {
+    // Optimistic pass: after the first tile no row maximum is taken; p = exp2(score - reference) is exact in bf16 / fp32 whatever its
+    // exponent, so the result only depends on the reference through overflow.  A row whose sum left [0, 2^LZ_LIMIT) (or is NaN) ran
+    // away from its first tile's maximum by more than any trained attention does; the workgroup then repeats the sweep with the
+    // per-tile maximum and the rebase (the decision is workgroup-uniform: the waves share the K/V ring and its barriers).
+    constexpr float LZ_LIMIT = 1.8446744e19f;                // 2^64
+    constexpr bool safe_only = DD_ATTN_SAFE_ONLY;
+    bool bad = safe_only;
+    if (!safe_only) {
+      sweep(F_{});
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float l = ONES ? o[qt][DVT - 1][(D % 16) % 4] : lsum[qt];     // ONES: only the owning lanes hold the sum, the others hold O columns (bounded by it times |v|)
+        bad = bad || !(fabsf(l) < LZ_LIMIT);
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bad = bad || !(fabsf(o[qt][dt][r]) < 3.0e38f);
+      }
+      bad = __syncthreads_or(bad);
+    }
+    if (bad) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = -INFINITY; lsum[qt] = 0.f; negm[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      sweep(T_{});
+    }
+  } else {
+    sweep(T_{});
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -612,7 +675,10 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
     tile_load<KT, PREFETCH ? DPK : 32>(kreg, kg, p.ldk, p.Nk, D, tid);
     tile_load<KT, PREFETCH ? DPK : 32>(vreg, vg, p.ldv, p.Nk, D, tid);
   }
-  for (int k0 = 0; k0 < p.Nk; k0 += KT) {
+  // RAGGED (keys beyond Nk: only the last tile of a ragged key count) is compile-time: as a run-time test the compiler kept the 64
+  // selects and their compares in every tile
+  auto tile = [&](auto ragged_c, int k0) {
+    constexpr bool ragged = decltype(ragged_c)::value;
     __syncthreads();
     if (PREFETCH) {
       tile_store<KT, PREFETCH ? DPK : 32>(kreg, Ks, S, tid);
@@ -644,17 +710,14 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
           }
         }
       }
-      const bool ragged = k0 + KT > p.Nk;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = k0 + kt * 16 + 4 * g + r;
-            // keys beyond Nk only exist in the last tile of a ragged key count (wave-uniform test: no per-score select otherwise)
             float pr = __builtin_amdgcn_exp2f(PS ? st[qt][kt][r] : st[qt][kt][r] * sl2);
-            if (ragged && key >= p.Nk) pr = 0.f;
+            if constexpr (ragged) { if (k0 + kt * 16 + 4 * g + r >= p.Nk) pr = 0.f; }
             st[qt][kt][r] = pr * dpt[qt][kt][r];
           }
 #pragma unroll
@@ -669,6 +732,11 @@ __global__ __launch_bounds__(256, DD_AW_DQ(D)) void attn_bwd_dq_kernel(AttnParam
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf, dsf[qt][c], dq[qt][dt], 0, 0, 0);
       }
+  };
+  {
+    int k0 = 0;
+    for (; k0 + KT <= p.Nk; k0 += KT) tile(std::false_type{}, k0);
+    if (k0 < p.Nk) tile(std::true_type{}, k0);
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {

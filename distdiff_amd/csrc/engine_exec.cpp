@@ -109,7 +109,9 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
           // LayerNorm row partials for the op that follows: only when the kernel the launcher picks for this shape has the form
           p.rowpart = c.rowpart; p.rowpart_ld = op.rowstat_ld;
           int spans = 0;
-          if (c.rowpart && conv_gemm_can_emit_rowstats(p, c.partial_cap, &spans) && spans <= op.rowstat_ld) { p.flags |= CF_ROWSTATS; P.row_spans[i] = spans; }
+          // (an op that is also a GroupNorm-partials producer keeps CF_STATS: one statistics epilogue per launch, and the consumer of the
+          // row partials falls back to its own statistics pass through row_spans == 0)
+          if (!op.part && c.rowpart && conv_gemm_can_emit_rowstats(p, c.partial_cap, &spans) && spans <= op.rowstat_ld) { p.flags |= CF_ROWSTATS; P.row_spans[i] = spans; }
           else { p.rowpart = nullptr; P.row_spans[i] = 0; }
         }
         if (op.use_table && c.img_bias > 0 && w->bias_table_img) {

@@ -5,14 +5,10 @@
 #define S(x) ((hipStream_t)(x))
 extern "C" {
 int dd_op_conv_gemm(const ConvGemmParams* p, size_t cap, void* st) {
-  // One-tap, stride-1, same-size launches take the persistent kernel's pointwise path, which does not read the tap table: it IS the
-  // centre tap (what every packer emits for 1x1 / linear layers).  A caller-supplied table with another single tap is rejected here
-  // (this diagnostic entry point may synchronise; the engine's own launches come from the packers).
-  if (p->ntaps == 1 && p->stride == 1 && p->H == p->Ho && p->W == p->Wo && p->shift == 0 && p->taptab) {
-    int tap = 0;
-    if (hipMemcpy(&tap, p->taptab, sizeof tap, hipMemcpyDeviceToHost) != hipSuccess) return (int)hipErrorInvalidValue;
-    if (tap != ((32 << 6) | 32)) return (int)hipErrorInvalidValue;
-  }
+  // Stream-asynchronous like every other launcher (no host round trip: graph-capturable, and back-to-back launches stay back to back).
+  // Contract: a one-tap, stride-1, same-size launch is a 1x1 / linear layer and takes the persistent kernels' pointwise path, which
+  // does not read the tap table -- it IS the centre tap, what every packer emits for such layers.  The host side that owns the table
+  // validates it when the weights are packed (distdiff_amd/ops.py: PackedConv.taptab_host), not here per launch.
   return (int)launch_conv_gemm(*p, cap, S(st));
 }
 int dd_op_groupnorm_fwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_fwd(*p, S(st)); }

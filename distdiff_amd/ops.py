@@ -39,6 +39,7 @@ class PackedConv:
                               wp.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), out4)
         self.w = torch.from_numpy(wp.view(np.int16)).to(device).view(torch.bfloat16)
         self.taptab = torch.from_numpy(tt).to(device)
+        self.taptab_host = tt                     # host copy: contract checks without a device round trip (conv_gemm)
         self.geglu = bool(geglu) and mode == 0   # in dgrad form the permutation applies to K only
         self.bias = None
         if bias is not None:
@@ -109,6 +110,10 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
     p = ConvGemmParams()
     M = B * Ho * Wo
     ncols = pk.N // 2 if pk.geglu else pk.N
+    # pointwise contract of dd_op_conv_gemm: a one-tap, stride-1, same-size launch does not read its tap table (it IS the centre tap);
+    # checked here on the host copy kept at pack time, so the launch itself stays stream-asynchronous
+    if pk.ntaps == 1 and stride == 1 and (H, W) == (Ho, Wo) and shift == 0 and int(pk.taptab_host[0]) != ((32 << 6) | 32):
+        raise RuntimeError("conv_gemm: a one-tap stride-1 launch must be the centre tap (got %#x)" % int(pk.taptab_host[0]))
     if y is None:
         y = torch.empty((M, ncols), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     p.x, p.w, p.taptab, p.y = _ptr(x), _ptr(pk.w), _ptr(pk.taptab), _ptr(y)

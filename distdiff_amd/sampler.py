@@ -15,10 +15,14 @@ def _prototypes(engine, total_global_proto, total_local_proto):
     uploaded when the caller hands over different tensors than last time (None, None = keep what dd_set_prototypes installed)."""
     if total_global_proto is None and total_local_proto is None:
         return
-    key = (id(total_global_proto), id(total_local_proto))
-    if getattr(engine, "_shim_proto_key", None) != key:
+    # the cache holds the tensors themselves (an id() alone can be recycled by a new tensor at the same address) and their in-place
+    # modification counters, so a table that was freed, replaced or updated in place is uploaded again
+    last = getattr(engine, "_shim_protos", None)
+    cur = (total_global_proto, total_local_proto)
+    ver = tuple(getattr(t, "_version", None) for t in cur)
+    if last is None or last[0][0] is not cur[0] or last[0][1] is not cur[1] or last[1] != ver:
         engine.set_prototypes(total_global_proto, total_local_proto)
-        engine._shim_proto_key = key
+        engine._shim_protos = (cur, ver)
 
 
 def denoise_one_step(latents, noise_scheduler, t, unet, prompt_embeds, class_labels):

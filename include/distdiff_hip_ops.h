@@ -34,8 +34,9 @@ struct AttnParams;
 struct ConvF32Params;
 
 /* taptab contract: entry t = ((dy + 32) << 6) | (dx + 32).  A launch with ONE tap, stride 1 and an output of the input's size is a
- * pointwise (1x1 / linear) layer and must carry the centre tap (dy = dx = 0) -- the persistent kernel skips the table for it; any
- * other single tap is rejected with hipErrorInvalidValue. */
+ * pointwise (1x1 / linear) layer and must carry the centre tap (dy = dx = 0) -- the persistent kernels skip the table for it.  The
+ * entry point is stream-asynchronous and does not read device memory: the owner of the table checks it on the host when the weights
+ * are packed (distdiff_amd/ops.py raises on any other single tap). */
 int dd_op_conv_gemm(const struct ConvGemmParams* p, size_t partial_cap_bytes, void* stream);
 int dd_op_groupnorm_fwd(const struct GroupNormParams* p, void* stream);
 int dd_op_groupnorm_bwd(const struct GroupNormParams* p, void* stream);

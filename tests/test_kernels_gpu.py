@@ -207,15 +207,16 @@ def test_linear_epilogues(ops):
 
 def test_pointwise_launch_requires_the_centre_tap(ops):
     """dd_op_conv_gemm: a one-tap, stride-1, same-size launch is a 1x1 / linear layer; the persistent kernel does not read its tap
-    table, so the ABI rejects a table that holds anything but the centre tap instead of silently computing the centre tap."""
+    table, so the host side rejects a table that holds anything but the centre tap instead of silently computing the centre tap --
+    on the host copy kept at pack time (the launch entry point never synchronises)."""
     from distdiff_amd import _lib
     g = torch.Generator().manual_seed(12)
     M, K, N = 2048, 256, 256
     x = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
     pk = ops.PackedConv(bf(torch.randn(N, K, generator=g) / 16), 0)
-    assert int(pk.taptab[0]) == (32 << 6) | 32
+    assert int(pk.taptab[0]) == (32 << 6) | 32 == int(pk.taptab_host[0])
     ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
-    pk.taptab[0] = ((32 + 1) << 6) | 32          # dy = +1
+    pk.taptab[0] = pk.taptab_host[0] = ((32 + 1) << 6) | 32          # dy = +1
     with pytest.raises(RuntimeError):
         ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
 
@@ -343,6 +344,28 @@ def test_linear_emits_layernorm_row_partials(ops, M, K, N):
     assert_close(stats[:, 1], (ref.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=4e-3, atol=1e-4, what="rstd from partials")
 
 
+def test_layernorm_row_partials_with_rows_far_from_zero(ops):
+    """CF_ROWSTATS uses one-pass fp32 (sum, sum^2) of the fp32 values in front of their bf16 rounding; the folded GEMM then multiplies
+    the bf16-stored rows.  With |row mean| = 50 x the row's standard deviation (beyond it bf16 storage itself -- quantum |mean| / 256 --
+    drowns the row's variation) the one-pass variance must still give the rstd of the STORED rows to 2 %, the mean to 1e-3 relative."""
+    g = torch.Generator().manual_seed(79)
+    M, K, N = 16384, 320, 320
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    res = bf(torch.randn(M, N, generator=g) + (torch.randint(0, 2, (M, 1), generator=g) * 2 - 1) * 70.0)
+    pk = ops.PackedConv(w, 0)
+    spans = N // 80
+    part = torch.zeros((M, spans, 2), device="cuda", dtype=torch.float32)
+    y = ops.conv_gemm(x.to(torch.bfloat16).cuda(), pk, 1, M, 1, M, 1, res=res.to(torch.bfloat16).cuda(), ksplit=1, rowpart=part)
+    stats = ops.layernorm_stats(y, 1e-5, rowpart=part, spans=spans)
+    torch.cuda.synchronize()
+    ys = y.float().cpu()                                  # the stored (bf16-rounded) rows the consumer normalises
+    ratio = (ys.mean(1).abs() / ys.std(1)).median()
+    assert 40 < float(ratio) < 60, float(ratio)
+    assert_close(stats[:, 0], ys.mean(1), rtol=1e-3, atol=1e-3, what="mean from partials, shifted rows")
+    assert_close(stats[:, 1], (ys.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-2, atol=1e-4, what="rstd from partials, shifted rows")
+
+
 ATT_CASES = [("self_d40", 2, 8, 256, 256, 40), ("self_d64", 1, 2, 200, 200, 64), ("self_d80", 1, 4, 128, 128, 80),
              ("self_d160", 1, 2, 64, 64, 160), ("cross77_d40", 2, 8, 256, 77, 40), ("cross77_d160", 1, 8, 64, 77, 160),
              ("self_d32", 1, 2, 96, 96, 32), ("vae_d512", 1, 1, 256, 256, 512)]
@@ -418,6 +441,30 @@ def test_attention_with_prescaled_query(ops, case):
     if not cross:
         assert_close(dk.reshape(B, Nk, H, D), gk, rtol=3e-2, atol=3e-3, what=name + " dK")
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
+
+
+@pytest.mark.parametrize("D,H,Nq", [(40, 8, 512), (80, 4, 192), (64, 2, 128)])
+def test_attention_reference_runaway_takes_the_safe_sweep(ops, D, H, Nq):
+    """The lazy forward's optimistic sweep takes no row maximum after the first key tile; rows whose later scores run away from the
+    first tile's maximum by more than 2^64 (here: up to +150 in the log2 domain, far beyond anything a trained attention produces) must
+    be caught by the row-sum check and recomputed by the safe sweep (per-tile maximum + rebase) -- same results as fp32 softmax."""
+    B, Nk = 1, 1024 + 40                                  # ragged last tile as well
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn(H, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    a = math.sqrt(150.0)
+    qp = bf(torch.randn(B, Nq, H, D, generator=g) * 0.3 + a * u)
+    k = bf(torch.randn(B, Nk, H, D, generator=g) + (torch.linspace(0, 1, Nk)[None, :, None, None] * a) * u)
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    ln2 = math.log(2.0)
+    s = torch.einsum("bqhd,bkhd->bhqk", qp, k) * ln2
+    assert float(s.max() - s[..., :64].max()) > 64 * ln2       # the run-away the optimistic sweep cannot represent
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    o, lse = ops.attention(dev(qp, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, ln2, q_prescaled=True)
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref, rtol=2e-2, atol=2e-3, what="runaway O")
+    assert_close(lse, torch.logsumexp(s, dim=-1), rtol=1e-3, atol=2e-3, what="runaway LSE")
 
 
 @pytest.mark.parametrize("D,H", [(40, 8), (80, 8)])
