@@ -35,10 +35,13 @@ __device__ __forceinline__ bf16x8 lds_col_frag(const unsigned char* base, int r0
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
-// v_max_f32 / v_max3_f32 as single instructions: fmaxf() on MFMA results makes the compiler put a canonicalising v_max_f32 v, v, v in
-// front (5 of the 16 max instructions per query tile and KV tile in the ISA of the forward kernel, which is bound by the vector issue port)
-__device__ __forceinline__ float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// Maxima of MFMA results as single instructions the COMPILER sees: fmaxf() makes it put a canonicalising v_max_f32 v, v, v in front of
+// every operand that comes out of an MFMA, and an inline-asm v_max3_f32 (round 3) is invisible to its hazard recogniser -- nothing then
+// guarantees the wait states between an MFMA and a vector instruction that reads its result, and with one MFMA per score tile (d = 32)
+// the asm read registers the MFMA had not written yet (NaN outputs; found with tools/attn_dbg.py).  v_med3_f32(a, b, +inf) = max(a, b) is
+// a target intrinsic: no canonicalisation, hazards handled.  The maxima only run in the first key tile and the safe sweep now.
+__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax2(vmax2(a, b), c); }
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   uint4 u;
   u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);

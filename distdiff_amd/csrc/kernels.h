@@ -33,7 +33,7 @@ enum ConvFlags {
                      // staged input tile (once per tile and 64-channel chunk, zero padding kept) instead of a separate apply pass; gn_coef =
                      // per-(image, channel) (a, b) = (rstd * gamma, beta - mean * rstd * gamma).  conv_gemm_can_fold_gn() says when.
   CF_ROWSTATS = 2048 // also emit, per output row and per 80-/64-column wave span, (sum v, sum v^2) of the fp32 values in front of their bf16 rounding
-                     // (one-pass fp32: rstd of the stored rows within 2 % up to |mean| = 50 std, tests/test_kernels_gpu.py) into rowpart: the
+                     // (one-pass fp32: rstd of the stored rows within 4 % up to |mean| = 50 std, tests/test_kernels_gpu.py) into rowpart: the
                      // LayerNorm that consumes this tensor takes its row statistics from there (conv_gemm_can_emit_rowstats)
 };
 

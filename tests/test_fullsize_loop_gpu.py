@@ -28,8 +28,8 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 B = 32
 # bounds (worst row); see the module docstring
-C1 = {"z_rel": 0.05, "psnr": 30.0, "img_max": 0.25, "u8_diff": 0.60, "u8_gt2": 0.10, "score_rel": 0.01}
-C3 = {"z_rel": 0.05, "psnr": 30.0, "img_max": 0.25, "u8_diff": 0.60, "u8_gt2": 0.10, "score_rel": 0.01}
+C1 = {"z_rel": 0.03, "psnr": 40.0, "img_max": 0.10, "u8_diff": 0.85, "u8_gt2": 0.25, "score_rel": 0.002}
+C3 = {"z_rel": 0.03, "psnr": 40.0, "img_max": 0.10, "u8_diff": 0.85, "u8_gt2": 0.25, "score_rel": 0.002}
 
 
 def rel(a, b):
