@@ -33,8 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0,
-                    help="images per step per GPU; 0 = the largest of 32 / 16 / 8 whose workspace (7.6 GB per image at 512x512: two activation "
-                         "stashes for the chained guided steps) fits the free HBM of every rank")
+                    help="images per step per GPU; 0 = the largest of 32 / 16 / 8 whose workspace (5.7 GB per image at 512x512: two activation "
+                         "stashes for the chained guided steps + the gradient slab) fits the free HBM of every rank")
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny", "sdxl"],
                     help="sd15 = BASELINE configs[1] (the metric's workload); sdxl = the SDXL-base UNet at 1024x1024 (configs[4] structure, bf16)")
     ap.add_argument("--guidance", default="transform_guidance", choices=["transform_guidance", "direct_guidance", "none"])
@@ -140,7 +140,8 @@ def cli_rate(eng, cfg, sched, a, B, n_units=128):
     try:
         args = G.parse_args(["--synthetic", str(n_units), "--num_images_per_prompt", "1", "--output_dir", out, "--engine_batch", str(B),
                              "--guidance_type", a.guidance if a.guidance != "none" else "", "--strength", str(a.strength),
-                             "--guidance_step", str(a.guidance_step), "--guidance_period", str(a.guidance_period), "--seed", "42"])
+                             "--guidance_step", str(a.guidance_step), "--guidance_period", str(a.guidance_period), "--seed", "42",
+                             "--total_split", "1", "--split", "0"])
         ds = G.ExpansionDataset.synthetic(cfg, n_units, 100, seed=7)
         torch.cuda.synchronize()
         t0 = time.time()

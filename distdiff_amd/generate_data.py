@@ -369,13 +369,14 @@ def load_config_and_weights(args, B):
 
 def auto_engine_batch(args, dev, distributed=False):
     """Static engine batch when --engine_batch is not given: 8 for --tiny; at 512x512 the largest of 32 / 16 / 8 whose workspace fits the
-    free HBM (the two activation stashes of the chained guided steps are ~7.5 GB per image: 239 / 122 / 65 GB; 32 images per launch
+    free HBM (the two activation stashes of the chained guided steps + the liveness-packed gradient slab are ~5.7 GB per image: 187 GB at
+    32 images; 32 images per launch
     are 4 % faster than 16 on an MI355X); 16 otherwise.  Ranks of one run agree on the minimum."""
     if args.tiny:
         return 8
     B = 16
     if args.resolution == 512 and torch.device(dev).type == "cuda" and torch.cuda.is_available():
-        per_image = 7.6e9 if args.guidance_type else 3.0e9
+        per_image = 5.8e9 if args.guidance_type else 3.0e9
         free = torch.cuda.mem_get_info(torch.device(dev))[0] - 12e9
         B = 32 if free >= 32 * per_image else 16 if free >= 16 * per_image else 8
         if distributed:

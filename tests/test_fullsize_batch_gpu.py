@@ -46,10 +46,13 @@ def world(request, hip_lib):
     from distdiff_amd.scheduler import DDIMSchedule
     from distdiff_amd.weights import synthetic_weights
     B = request.param
-    free, _ = torch.cuda.mem_get_info()
-    need = (7.6e9 * B + 8e9)          # two chained activation stashes: ~7.5 GB per image
+    free, total = torch.cuda.mem_get_info()
+    need = (5.8e9 * B + 8e9)          # two chained activation stashes + the liveness-packed gradient slab: 5.7 GB per image
     if free < need:
-        pytest.skip("engine batch %d needs ~%.0f GB of HBM, %.0f GB free" % (B, need / 1e9, free / 1e9))
+        # the benchmarked batch must fit an EMPTY MI355X: only a smaller device is a reason to skip
+        if total < 280e9:
+            pytest.skip("engine batch %d needs ~%.0f GB of HBM, device has %.0f GB" % (B, need / 1e9, total / 1e9))
+        pytest.fail("engine batch %d needs ~%.0f GB of HBM, only %.0f of %.0f GB free on this device" % (B, need / 1e9, free / 1e9, total / 1e9))
     fx1 = torch.load(os.path.join(HERE, "golden", "fullsize_fixture.pt"), weights_only=False)
     fx2 = torch.load(os.path.join(HERE, "golden", "fullsize_p2_fixture.pt"), weights_only=False)
     cfg = sd15_config(latent_size=64, max_batch=B)
@@ -161,26 +164,27 @@ def test_transform_guidance_two_chained_steps_every_row(world):
 
 
 def test_direct_guidance_every_row(world):
-    """configs[3]'s guided step (generate_data.py:735-767, C = 196): "a" rows against fullsize_fixture.pt, "b" rows (no oracle run of
-    their own) must agree with each other -- they are the same computation at different batch positions."""
+    """configs[3]'s guided step (generate_data.py:735-767, C = 196) on every row against its OWN oracle run: "a" rows against
+    fullsize_fixture.pt, "b" rows against fullsize_direct_b_fixture.pt (make_fullsize_direct_b_fixture.py); both at the oracle's image."""
     w = world
     eng, rows, inp, fx1, B = w["eng"], w["rows"], w["inp"], w["fx1"], w["B"]
+    fxb = torch.load(os.path.join(HERE, "golden", "fullsize_direct_b_fixture.pt"), weights_only=False)
+    assert fxb["target"] == 33
     w["schedule"](2)
     eng.set_prototypes(w["da"]["Pc196"], w["da"]["Pg196"])
     si = fx1["step_index"]
     z0 = inp["z"] * (1 + inp["e"]) + inp["b"]
-    ia = [i for i, r in enumerate(rows) if r == "a"]
-    ib = [i for i, r in enumerate(rows) if r == "b"]
     imgs = torch.cat([fx1["image"] if r == "a" else w["fx2"]["b"]["image_1"].float() for r in rows])
     eng.set_guide_image(imgs)
     zn, x0, score, gz = eng.direct_guidance(z0, inp["t196"], si)
     sc = eng.image_scores().cpu()
     eng.set_guide_image(None)
-    s_ref = float(fx1["direct_score"])
-    for i in ia:
-        assert abs(float(sc[i]) - s_ref) <= 1e-4 * abs(s_ref)
-        assert rel(gz[i:i + 1], fx1["direct_gz"]) < 0.06, (i, rel(gz[i:i + 1], fx1["direct_gz"]))
-        assert rel(zn[i:i + 1], fx1["direct_z_next"]) < 0.03 and rel(x0[i:i + 1], fx1["x0"]) < 0.03
-    for i in ib[1:]:
-        assert rel(gz[i:i + 1], gz[ib[0]:ib[0] + 1]) < 1e-2 and rel(zn[i:i + 1], zn[ib[0]:ib[0] + 1]) < 1e-3
-    print("B=%d direct: row-a g_z rel %.4f" % (B, rel(gz[ia[0]:ia[0] + 1], fx1["direct_gz"])))
+    worst = {"a": [0.0, 0.0, 0.0], "b": [0.0, 0.0, 0.0]}
+    for i, r in enumerate(rows):
+        f = fx1 if r == "a" else fxb
+        s_ref = float(f["direct_score"])
+        assert abs(float(sc[i]) - s_ref) <= 1e-4 * abs(s_ref), (i, r, float(sc[i]), s_ref)
+        e = (rel(gz[i:i + 1], f["direct_gz"]), rel(zn[i:i + 1], f["direct_z_next"]), rel(x0[i:i + 1], f["x0"]))
+        assert e[0] < 0.06 and e[1] < 0.03 and e[2] < 0.03, (i, r, e)
+        worst[r] = [max(a_, b_) for a_, b_ in zip(worst[r], e)]
+    print("B=%d direct guidance, worst row (g_z, z_next, x0): a %.4f %.4f %.4f | b %.4f %.4f %.4f" % tuple([B] + worst["a"] + worst["b"]))

@@ -678,6 +678,11 @@ STATS_CASES = [
     ("halo_256", 12, 64, 256, 64, 64, 3, False),               # 256 x 256 tiles
     ("halo_w256_res", 1, 64, 256, 256, 256, 3, True),          # 2 x 128-pixel tiles: partial blocks of 64 rows inside a tile row
     ("halo_n128_res", 1, 64, 128, 512, 512, 3, True),          # 512 x 128 tiles
+    # channels far from zero: every GroupNorm group's bias is shifted by +-50 standard deviations of the convolution's output, so the
+    # one-pass (mean, M2) of a 64-row block is the small difference sq - sa * mean of two numbers 2500 x larger (fp32 partials, Chan merge)
+    ("halo_320_res_shift50", 48, 128, 320, 32, 32, 3, True, 50.0),
+    ("fe_1x1_res_shift50", 2, 320, 640, 64, 64, 1, True, 50.0),
+    ("two_wg_128x128_shift50", 1, 128, 128, 256, 256, 3, True, 50.0),
 ]
 
 
@@ -685,11 +690,14 @@ STATS_CASES = [
 def test_conv_emits_groupnorm_partials(ops, case):
     """CF_STATS: the implicit-GEMM epilogue also emits per-(64-row block, channel) partial (mean, M2) of the values it stores, and
     GroupNorm(+SiLU) computed from those partials (no statistics pass over the tensor) matches torch on the conv output."""
-    name, B, Cin, Cout, H, W, k, with_res = case
+    name, B, Cin, Cout, H, W, k, with_res = case[:8]
+    shift = case[8] if len(case) > 8 else 0.0
     g = torch.Generator().manual_seed(len(name))
     x = bf(torch.randn(B, Cin, H, W, generator=g))
     w = bf(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
     bias = torch.randn(Cout, generator=g)
+    if shift:                                             # +-shift per GroupNorm group (32 groups)
+        bias = bias + shift * (torch.arange(Cout) // (Cout // 32) % 2 * 2 - 1).float()
     res = bf(torch.randn(B, Cout, H, W, generator=g)) if with_res else None
     ref = F.conv2d(x, w, bias, padding=k // 2) + (res if with_res else 0)
     M = B * H * W
@@ -706,7 +714,8 @@ def test_conv_emits_groupnorm_partials(ops, case):
     rows = ref.permute(0, 2, 3, 1).reshape(M // 64, 64, Cout)              # the fp32 values before the bf16 rounding of the store
     pm, pM2 = part[:, 64:, 0].cpu(), part[:, 64:, 1].cpu()
     assert_close(pm, rows.mean(1), rtol=2e-3, atol=2e-3, what=name + " partial mean")
-    assert_close(pM2, ((rows - rows.mean(1, keepdim=True)) ** 2).sum(1), rtol=2e-2, atol=2e-2, what=name + " partial M2")
+    # shifted: |mean| / std = 50 / sqrt(1 + res) -> the fp32 one-pass M2 of 64 values near 50 keeps ~1e-3 of 64 * var (measured), bound 5 %
+    assert_close(pM2, ((rows - rows.mean(1, keepdim=True)) ** 2).sum(1), rtol=5e-2 if shift else 2e-2, atol=2e-2, what=name + " partial M2")
     assert float(part[:, :64].abs().max()) == 0.0                          # nothing outside the op's channel range
     # GroupNorm from the partials
     G, eps = 32, 1e-5
