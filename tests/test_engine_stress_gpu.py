@@ -51,8 +51,9 @@ def stress(w, qk_gain=1.0, gn_shift=0.0, groups=32, where="first"):
 
 
 # (qk gain, where, GroupNorm shift, bound on eps rel-L2 or None = finite only): measured on MI355X, see the print of each case
-TINY_CASES = [(1.0, "first", 0.0, 0.03), (4.0, "first", 0.0, 0.08), (4.0, "all", 0.0, None), (1.0, "first", 10.0, 0.06), (1.0, "first", 50.0, 0.20),
-              (4.0, "first", 10.0, 0.10)]
+# measured: 0.0135 | 0.0184 | 0.389 (the oracle itself moves 0.286 under one bf16 rounding of z) | 0.0276 | 0.0976 | 0.0544
+TINY_CASES = [(1.0, "first", 0.0, 0.03), (4.0, "first", 0.0, 0.04), (4.0, "all", 0.0, None), (1.0, "first", 10.0, 0.045), (1.0, "first", 50.0, 0.15),
+              (4.0, "first", 10.0, 0.08)]
 
 
 @pytest.mark.parametrize("case", TINY_CASES, ids=lambda c: "qk%g%s_gn%g" % (c[0], c[1], c[2]))
@@ -116,7 +117,8 @@ def test_tiny_unet_and_guided_step_on_stressed_weights(hip_lib, case):
 
 
 # SD-1.5 widths at 512x512 (4096-token self-attention at d = 40, 8 heads): one UNet forward, B = 1 (CFG batch 2)
-FULL_CASES = [(4.0, "first", 0.0, 0.08), (4.0, "all", 0.0, None), (1.0, "first", 10.0, 0.06)]
+# measured: 0.0227 | 0.729 | 0.0284
+FULL_CASES = [(4.0, "first", 0.0, 0.04), (4.0, "all", 0.0, None), (1.0, "first", 10.0, 0.045)]
 
 
 @pytest.mark.parametrize("case", FULL_CASES, ids=lambda c: "qk%g%s_gn%g" % (c[0], c[1], c[2]))

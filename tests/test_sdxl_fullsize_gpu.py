@@ -60,3 +60,70 @@ def test_sdxl_base_unet_step_vjp_and_1024_decode(hip_lib):
         assert e[0] < 0.03 and e[1] < 0.03 and e[2] < 0.05 and e[3] < 0.05 and e[4] < 0.03, e
     finally:
         eng.close()
+
+
+def test_sdxl_base_guided_loop_1024(hip_lib):
+    """configs[4] in bf16, the GUIDED path at full size: `dd_expand` on the SDXL-base UNet at 1024x1024 -- add_noise, 5 executed steps of a
+    10-step schedule, transform guidance with two chained guided steps at t = 301 (UNet + 1024x1024 decoder + ResNet-50 + energy,
+    forward and hand-derived VJP) + the re-step, final decode -- against the fp32 oracle's loop (tests/golden/sdxl_loop_fixture.pt,
+    make_sdxl_loop_fixture.py; the guide's masks at each side's OWN images).  Stated: chained-step x0 (forward only), guidance score,
+    (ge, gb), latents after the transform update, final latents, final image PSNR / max abs / uint8 bytes."""
+    import math
+    from make_fullsize_fixture import inputs as proto_inputs
+    from make_sdxl_loop_fixture import loop_inputs
+    from distdiff_amd.config import sd15_config, sdxl_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule, guide_window, start_index
+    from distdiff_amd.weights import synthetic_weights
+    free, total = torch.cuda.mem_get_info()
+    if free < 110e9:
+        if total < 280e9:
+            pytest.skip("the SDXL engine at 1024x1024 with two chained stashes needs ~90 GB of HBM")
+        pytest.fail("only %.0f of %.0f GB of HBM free" % (free / 1e9, total / 1e9))
+    fx = torch.load(os.path.join(HERE, "golden", "sdxl_loop_fixture.pt"), weights_only=False)
+    cfg = sdxl_config(latent_size=128, max_batch=1)
+    w = synthetic_weights(cfg, seed=0, num_classes=100)
+    chk = float(sum(v.double().sum() for v in w["unet"].values()))
+    assert abs(chk - fx["weights_checksum"]) <= 1e-6 * abs(fx["weights_checksum"]), "synthetic weights differ from the fixture's"
+    P = fx["guidance_period"]
+    eng = Engine(cfg, w, enable_grad=True, max_guidance_period=P)
+    del w
+    try:
+        sched = DDIMSchedule(cfg.scheduler)
+        ts = sched.set_timesteps(fx["n_steps"])
+        si = start_index(fx["strength"], fx["n_steps"])
+        first, cnt = guide_window(fx["n_steps"], fx["guidance_step"], P)
+        assert si == fx["start_index"] and [ts[first + k] for k in range(cnt)] == fx["guide_timesteps"]
+        eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_scale=7.5, gs=1.0, ls=1.0, rho=10.0, constraint_value=0.2,
+                         guidance_period=P)
+        d = loop_inputs(cfg)
+        proto = proto_inputs(sd15_config(latent_size=64, max_batch=1))
+        eng.set_prototypes(proto["Pc100"], proto["Pg100"])
+        eng.set_prompt(torch.cat([d["neg"], d["pos"]]).cuda())
+        eng.set_added_cond(d["te"], d["ti"])
+        eng.set_sample_weights([1.0])
+        z, img, score = eng.expand(d["latents"], d["noise"], d["e"], d["b"], d["target"], si, "transform_guidance", first, cnt)
+        u8 = eng.image_to_u8(img).cpu()
+        ref_img = fx["image_u8"].float().permute(0, 3, 1, 2) / 255.0
+        mse = float(((img.cpu() - ref_img) ** 2).mean())
+        psnr = 10.0 * math.log10(1.0 / max(mse, 1e-20))
+        du8 = (u8.int() - fx["image_u8"].int()).abs()
+        zf = rel(z, fx["z_final"])
+        srel = abs(float(score) - float(fx["score"])) / abs(float(fx["score"]))
+        # the pieces, step by step through the ABI
+        zc = eng.add_noise(d["latents"], d["noise"], si)
+        zs = [rel(zc, fx["traj"][0:1])]
+        zg = None
+        for k, i in enumerate(range(si, fx["n_steps"])):
+            if i == first:
+                zc, _, gz = eng.transform_guidance(zc, d["target"], d["e"], d["b"], first, cnt)
+                zg = rel(zc, fx["z_guided"])
+            zc, _ = eng.denoise_step(zc, i)
+            zs.append(rel(zc, fx["traj"][k + 1:k + 2]))
+        assert torch.equal(zc, z), "dd_expand and the step-by-step ABI calls differ"
+        print("SDXL-base guided loop 1024x1024: final latents %.4f | image PSNR %.2f dB (vs the oracle's uint8 image), u8 bytes differing %.3f (by > 2 "
+              "levels %.4f) | score rel %.5f | latents after the transform update %.4f | trajectory %s"
+              % (zf, psnr, float((du8 > 0).float().mean()), float((du8 > 2).float().mean()), srel, zg, " ".join("%.4f" % x for x in zs)))
+        assert zf < 0.04 and psnr > 38.0 and srel < 0.005 and zg < 0.05, (zf, psnr, srel, zg)
+    finally:
+        eng.close()
