@@ -23,7 +23,7 @@ for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         if "attn_fwd" not in r["Kernel_Name"]: continue
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
 with open(root + "/../attn_pmc.txt", "w") as out:
-    out.write("== attn_fwd_dma_kernel<40, 2, 64, 8>, B 32 x 8 heads x 4096 x 4096 (per launch)\n")
+    out.write("== attn_fwd_dma_kernel<40, 2, 64, 8, lazy>, B 32 x 8 heads x 4096 x 4096, prescaled query (per launch)\n")
     for c in sorted(acc):
         out.write("  %-32s %16.0f\n" % (c, acc[c] / cnt[c]))
 print(open(root + "/../attn_pmc.txt").read())
