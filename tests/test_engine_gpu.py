@@ -392,3 +392,57 @@ def test_graph_replay_of_the_plain_step_is_bitwise_identical(hip_lib, fx):
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = [l for l in r.stdout.splitlines() if l.startswith("SUM")][0]
     assert res["0"] == res["1"], res
+
+
+@pytest.mark.parametrize("which", ["tiny", "sd15_256px"])
+def test_gradient_slab_by_liveness_is_bitwise_identical(hip_lib, which):
+    """plan_grad_memory (engine_graph.cpp): gradient buffers share bytes when their live intervals in the reverse run are disjoint.  The
+    guided results -- updated latents, scores, dE/dz0 of the chained transform guidance and of direct guidance -- must be BITWISE those of
+    one private range per tensor (DD_NO_GRAD_REUSE=1), twice in a row (stale bytes of a previous run in a shared range must not leak), and
+    the workspace must shrink.  tiny config and SD-1.5 widths at 256x256 (every op kind of the three programs)."""
+    from distdiff_amd.config import sd15_config, tiny_config
+    from distdiff_amd.engine import Engine
+    from distdiff_amd.scheduler import DDIMSchedule
+    from distdiff_amd.weights import synthetic_weights
+    cfg = tiny_config(max_batch=2) if which == "tiny" else sd15_config(latent_size=32, max_batch=2)
+    ncls = 5 if which == "tiny" else 100
+    w = synthetic_weights(cfg, seed=0, num_classes=ncls)
+    g = torch.Generator().manual_seed(9)
+    L, D = cfg.latent_size, cfg.guide.feature_dim
+    z = torch.randn(2, 4, L, L, generator=g)
+    e, b = torch.rand(2, 4, 1, 1, generator=g), torch.randn(2, 4, 1, 1, generator=g) * 0.3
+    emb = torch.randn(4, cfg.text_len, cfg.unet.cross_attention_dim, generator=g)
+    Pc = torch.nn.functional.normalize(torch.randn(ncls, D, generator=g), dim=-1)
+    Pg = torch.nn.functional.normalize(torch.randn(ncls, 3, D, generator=g), dim=-1)
+    tg = torch.tensor([1, 3])
+    outs, sizes = [], []
+    old = os.environ.pop("DD_NO_GRAD_REUSE", None)
+    try:
+        for flag in (None, "1"):
+            if flag:
+                os.environ["DD_NO_GRAD_REUSE"] = flag
+            eng = Engine(cfg, w, enable_grad=True, max_guidance_period=2)
+            os.environ.pop("DD_NO_GRAD_REUSE", None)
+            sched = DDIMSchedule(cfg.scheduler)
+            ts = sched.set_timesteps(10)
+            eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_period=2)
+            eng.set_prototypes(Pc, Pg)
+            eng.set_prompt(emb.cuda())
+            eng.set_sample_weights([1.0, 1.0])
+            res = []
+            for _ in range(2):
+                zt, st, gt = eng.transform_guidance(z, tg, e, b, 5, 2)
+                zd, x0, sd, gd = eng.direct_guidance(z, tg, 7)
+                res += [zt.cpu(), st.cpu(), gt.cpu(), zd.cpu(), sd.cpu(), gd.cpu()]
+            outs.append(res)
+            sizes.append(eng.workspace_bytes())
+            eng.close()
+    finally:
+        if old is not None:
+            os.environ["DD_NO_GRAD_REUSE"] = old
+    for x, y in zip(*outs):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+    for x, y in zip(outs[0][:6], outs[0][6:]):
+        assert torch.equal(x, y)                          # run 2 == run 1
+    assert sizes[0] < sizes[1], sizes
+    print("%s: workspace %.3f GB with liveness-packed gradients, %.3f GB with one range per tensor" % (which, sizes[0] / 1e9, sizes[1] / 1e9))
