@@ -237,7 +237,8 @@ void plan_backward(Program& P) {
 // in which the reverse run reads or writes it and the classes are packed first-fit: two classes share bytes only when their intervals are
 // disjoint.  Gradients that are read or written OUTSIDE run_bwd (program inputs / outputs: the sampler drivers seed and collect them)
 // and tensors with padding columns (which some kernels never write and others read: they must stay zero) keep a range of their own.
-// 32 images of the bench workload: the gradient slab shrinks from ~1.6 GB to ~0.3 GB per image.
+// 32 images of the bench workload: the gradient slab shrinks from 65.9 GB to 13.2 GB (UNet 38.7 -> 1.9, VAE decoder 64.4 -> 13.0, guide 1.47 ->
+// 0.22 GB); results are bit-identical (tests/test_engine_gpu.py::test_gradient_slab_by_liveness_is_bitwise_identical).
 void plan_grad_memory(Program& P) {
   if (!P.want_grad || getenv("DD_NO_GRAD_REUSE")) return;
   const int nt = (int)P.t.size(), nops = (int)P.ops.size();
@@ -249,7 +250,7 @@ void plan_grad_memory(Program& P) {
     if (op.kind == OP_CONV && op.res_alias) cls[find(op.res)] = find(op.y);
   const int LO = -1, HI = nops;
   std::vector<int> lo(nt, HI + 1), hi(nt, LO - 1);
-  std::vector<size_t> size(nt, 0), base_goff(nt, 0);
+  std::vector<size_t> size(nt, 0);
   std::vector<char> has_prod(nt, 0), has_cons(nt, 0);
   auto touch = [&](int id, int at) {
     if (id < 0 || !P.t[id].grad) return;
@@ -270,8 +271,7 @@ void plan_grad_memory(Program& P) {
       const size_t bytes = rup_sz((size_t)t.rows * t.ld * (t.gf32 ? 4 : 2), 256);
       if (size[c] && size[c] != bytes) throw std::runtime_error("grad plan: aliased gradients of different sizes");
       size[c] = bytes;
-      if (find(i) == i) base_goff[c] = t.goff;
-      else if (t.goff != P.t[c].goff) throw std::runtime_error("grad plan: aliased gradients at different offsets");
+      if (find(i) != i && t.goff != P.t[c].goff) throw std::runtime_error("grad plan: aliased gradients at different offsets");
     }
     const bool padded = t.C != t.ld && t.parent == i;
     bool produced = has_prod[i], consumed = has_cons[i];
