@@ -227,6 +227,12 @@ void plan_backward(Program& P) {
         break;
     }
   }
+  if (getenv("DD_PLAN_REPORT")) {
+    int nres = 0, nacc = 0, nalias = 0, ncopy = 0;
+    for (const Op& op : P.ops)
+      if (op.kind == OP_CONV && op.res >= 0 && P.t[op.res].grad) { ++nres; if (op.res_acc) ++nacc; else if (op.res_alias) ++nalias; else ++ncopy; }
+    fprintf(stderr, "[plan] residual gradients: %d convolutions with a residual, %d accumulate (add kernel), %d alias the output gradient, %d copy\n", nres, nacc, nalias, ncopy);
+  }
   plan_grad_memory(P);
 }
 
