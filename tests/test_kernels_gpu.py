@@ -321,6 +321,69 @@ def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
     assert_close(y, ref, rtol=1.5e-2, atol=2e-2, what="ln-folded linear")
 
 
+WS_CASES = [("n320_bias", 36928, 320, False, False, False, False), ("n320_res_rowstats", 36928, 320, True, False, True, False),
+            ("n960_lnfold", 33088, 960, False, True, False, False), ("n640_res_rowstats_views", 32768, 640, True, False, True, False),
+            ("geglu2560_lnfold_raw", 33088, 2560, False, True, False, True), ("geglu512_plain", 32832, 512, False, False, False, True)]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
+def test_weight_stationary_gemm(ops, case):
+    """gemm_ws.hip: the K = 320 pointwise layers of the transformer blocks at the 64x64 level (fused QKV, to_q, to_out + residual + row
+    statistics, proj_in, the GEGLU projection; diffusers BasicTransformerBlock) with the weights held in registers,
+    K split over the two waves of a SIMD and 64-row activation tiles streamed through LDS.  Ragged numbers of row tiles per workgroup,
+    1 / 2 / 3 / 10 column blocks, strided input / output / residual views, every epilogue flag; against torch on the same bf16 inputs."""
+    _, M, N, res, lnfold, rowstats, geglu = case
+    K = 320
+    g = torch.Generator().manual_seed(79)
+    x = bf(torch.randn(M, K, generator=g) * 1.3 + (torch.randn(M, 1, generator=g) * 0.6 if lnfold else 0.0))
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    views = "views" in case[0]
+    xs = torch.zeros((M, K + (64 if views else 0)), dtype=torch.bfloat16, device="cuda")
+    xs[:, -K:] = x.to(torch.bfloat16).cuda()
+    xd = xs[:, -K:]
+    ncols = N // 2 if geglu else N
+    ys = torch.zeros((M, ncols + (32 if views else 0)), dtype=torch.bfloat16, device="cuda")
+    yd = ys[:, :ncols]
+    rd = None
+    if res:
+        r = bf(torch.randn(M, N, generator=g) * 1.5 + 0.3)
+        rs_ = torch.zeros((M, N + (8 if views else 0)), dtype=torch.bfloat16, device="cuda")
+        rs_[:, :N] = r.to(torch.bfloat16).cuda()
+        rd = rs_[:, :N]
+    if lnfold:
+        gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+        ref = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), bf(w), bias)
+        wf = bf(w * gamma[None, :])
+        pk = ops.PackedConv(wf, 0, geglu=geglu, bias=bias + bf(w) @ beta)
+        c1 = ops.PackedConv(wf, 0, geglu=geglu, bias=wf.sum(dim=1)).bias
+        stats = ops.layernorm_stats(xd, 1e-5)
+    else:
+        ref = F.linear(x, bf(w), bias)
+        pk = ops.PackedConv(bf(w), 0, geglu=geglu, bias=bias)
+        c1 = stats = None
+    raw = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16) if geglu and lnfold else None
+    proj = ref
+    if geglu:
+        hh, gg = ref.chunk(2, dim=-1)
+        ref = hh * F.gelu(gg)
+    if res:
+        ref = ref + r
+    part = torch.zeros((M, N // 80, 2), device="cuda", dtype=torch.float32) if rowstats else None
+    ops.conv_gemm(xd, pk, 1, M, 1, M, 1, y=yd, res=rd, ksplit=1, ln_stats=stats, ln_c1=c1, rowpart=part, raw=raw, x_ld=xs.stride(0))
+    torch.cuda.synchronize()
+    assert_close(yd, ref, rtol=1.5e-2, atol=2e-2 if lnfold else 1e-3, what="ws gemm " + case[0])
+    if views:
+        assert float(ys[:, ncols:].float().abs().max()) == 0.0, "wrote outside the output view"
+    if raw is not None:
+        F2 = N // 2
+        perm = torch.tensor([(q // 32) * 16 + (q % 32) if (q % 32) < 16 else F2 + (q // 32) * 16 + (q % 32 - 16) for q in range(N)])
+        assert_close(raw, proj[:, perm], rtol=1.5e-2, atol=2e-2, what="ws geglu raw stash")
+    if rowstats:
+        assert_close(part[:, :, 0].sum(1), ref.sum(1), rtol=2e-3, atol=3e-2, what="ws row sums")
+        assert_close(part[:, :, 1].sum(1), (ref * ref).sum(1), rtol=2e-3, atol=3e-2, what="ws row sums of squares")
+
+
 @pytest.mark.parametrize("M,K,N", [(16384, 320, 320), (8192, 1280, 640), (3000, 640, 1280), (49152, 320, 320), (49152, 1280, 640)])
 def test_linear_emits_layernorm_row_partials(ops, M, K, N):
     """CF_ROWSTATS: the to_out / ff.net.2 / proj_in GEMMs emit (sum, sum^2) of every output row per 80-column wave span; the LayerNorm
