@@ -22,6 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] +
          "-I", os.path.join(HERE, "..", "include")]
 
 
+# per-file switches.  gemm_ws.hip: the SLP vectoriser turns the GEGLU / LayerNorm-fold epilogue into v_pk_fma_f32 / v_pk_mul_f32, which
+# cost more issue time beside MFMAs than the scalar pairs they replace (MI355X guide, cycle constants)
+PER_FILE = {"gemm_ws.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src, dst):
     if not os.path.exists(dst):
         return True
@@ -44,7 +49,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + PER_FILE.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print("[build]", os.path.basename(src), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -270,6 +270,7 @@ hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream)
 int gemm_pp_config(const ConvGemmParams& p);             // conv_halo.hip: pointwise ping-pong GEMM (narrow N)
 hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream);
 int gemm_ws_config(const ConvGemmParams& p);             // gemm_ws.hip: weight-stationary GEMM (K = 320 pointwise layers)
+int gemm_ws_rowstat_spans(const ConvGemmParams& p);
 hipError_t launch_gemm_ws(const ConvGemmParams& p, int tn, hipStream_t stream);
 void conv_gemm_big_tile(int cfg, int* bm, int* bn);
 hipError_t launch_conv_gemm_big(const ConvGemmParams& p, int cfg, hipStream_t stream);
@@ -352,7 +353,9 @@ bool conv_gemm_can_emit_rowstats(ConvGemmParams p, size_t partial_cap_bytes, int
   // the batched epilogue of the two-workgroup pointwise forms only (fast staging: Cin % 64 == 0, one tap, no upsample)
   if ((p.cin & 63) || p.shift || p.ntaps != 1 || p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return false;
-  { ConvGemmParams q = p; q.flags |= CF_ROWSTATS; if (gemm_ws_config(q) || gemm_pp_config(q)) { if (spans) *spans = p.N / 80; return true; } }
+  { ConvGemmParams q = p; q.flags |= CF_ROWSTATS;
+    if (gemm_ws_config(q)) { if (spans) *spans = gemm_ws_rowstat_spans(q); return true; }
+    if (gemm_pp_config(q)) { if (spans) *spans = p.N / 80; return true; } }
   int cfg, split;
   select_config(p, partial_cap_bytes, &cfg, &split);
   const int span = cfg ? conv_gemm_big_rowstat_span(cfg) : 0;

@@ -67,7 +67,7 @@ struct Builder {
           pr.stride == 1 && !pr.up && tx.parent == l.x && !pr.part) {
         l.rowstat_from = li - 1;
         pr.rowstat_emit = true;
-        pr.rowstat_ld = l.rowstat_ld = (tx.C + 63) / 64;
+        pr.rowstat_ld = l.rowstat_ld = (tx.C + 39) / 40;      // narrowest span any kernel form writes (gemm_ws.hip: 48 + 32 columns)
         P.scratch_rowpart = std::max(P.scratch_rowpart, (size_t)tx.rows * pr.rowstat_ld * 8);
       }
     }

@@ -321,8 +321,8 @@ def test_layernorm_folded_into_linear(ops, M, Cc, N, geglu):
     assert_close(y, ref, rtol=1.5e-2, atol=2e-2, what="ln-folded linear")
 
 
-WS_CASES = [("n320_bias", 36928, 320, False, False, False, False), ("n320_res_rowstats", 36928, 320, True, False, True, False),
-            ("n960_lnfold", 33088, 960, False, True, False, False), ("n640_res_rowstats_views", 32768, 640, True, False, True, False),
+WS_CASES = [("n320_bias", 36928, 320, False, False, False, False), ("n320_rowstats", 36928, 320, False, False, True, False), ("n320_res_rowstats_takes_the_pingpong_gemm", 36864, 320, True, False, True, False),
+            ("n960_lnfold", 33088, 960, False, True, False, False), ("n640_rowstats_views", 32768, 640, False, False, True, False),
             ("geglu2560_lnfold_raw", 33088, 2560, False, True, False, True), ("geglu512_plain", 32832, 512, False, False, False, True)]
 
 
@@ -369,7 +369,7 @@ def test_weight_stationary_gemm(ops, case):
         ref = hh * F.gelu(gg)
     if res:
         ref = ref + r
-    part = torch.zeros((M, N // 80, 2), device="cuda", dtype=torch.float32) if rowstats else None
+    part = torch.zeros((M, N // 40, 2), device="cuda", dtype=torch.float32) if rowstats else None
     ops.conv_gemm(xd, pk, 1, M, 1, M, 1, y=yd, res=rd, ksplit=1, ln_stats=stats, ln_c1=c1, rowpart=part, raw=raw, x_ld=xs.stride(0))
     torch.cuda.synchronize()
     assert_close(yd, ref, rtol=1.5e-2, atol=2e-2 if lnfold else 1e-3, what="ws gemm " + case[0])
@@ -394,7 +394,7 @@ def test_linear_emits_layernorm_row_partials(ops, M, K, N):
     bias = torch.randn(N, generator=g)
     res = bf(torch.randn(M, N, generator=g) * 2.0 + 0.5)
     pk = ops.PackedConv(w, 0, bias=bias)
-    spans = N // 80
+    spans = N // 40       # the narrowest span any kernel form writes (gemm_ws.hip: 48 + 32 columns); the spans a form does not write stay zero
     part = torch.zeros((M, spans, 2), device="cuda", dtype=torch.float32)
     y = ops.conv_gemm(x.to(torch.bfloat16).cuda(), pk, 1, M, 1, M, 1, res=res.to(torch.bfloat16).cuda(), ksplit=1, rowpart=part)
     torch.cuda.synchronize()

@@ -16,7 +16,7 @@ def run(M, K, N, res=False, lnfold=False, geglu=False, rowstats=False, raw=False
     y = torch.empty(M, ncols, dtype=torch.bfloat16, device="cuda")
     r = torch.randn(M, N, device="cuda").to(torch.bfloat16) if res else None
     st = torch.stack([torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")], 1).contiguous() if lnfold else None
-    part = torch.zeros((M, N // 80, 2), device="cuda") if rowstats else None
+    part = torch.zeros((M, N // 40, 2), device="cuda") if rowstats else None
     rw = torch.empty(M, N, dtype=torch.bfloat16, device="cuda") if raw else None
     f = lambda: ops.conv_gemm(x, pk, 1, M, 1, M, 1, y=y, res=r, ksplit=1, ln_stats=st, ln_c1=pc.bias if lnfold else None, rowpart=part, raw=rw)
     for _ in range(3):
@@ -35,6 +35,12 @@ def run(M, K, N, res=False, lnfold=False, geglu=False, rowstats=False, raw=False
 
 print("ws=" + os.environ.get("DD_GEMM_WS", "1"))
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 320
+if os.environ.get("WS_SHORT"):
+    run(262144, K, 320)
+    run(262144, K, 320, res=True, rowstats=True)
+    run(262144, K, 960, lnfold=True)
+    run(262144, K, 2560, lnfold=True, geglu=True)
+    sys.exit(0)
 for M in (262144, 131072):
     run(M, K, 320)
     run(M, K, 320, res=True, rowstats=True)
