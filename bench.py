@@ -24,7 +24,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-WORKSPACE_GB = {32: 200.0, 16: 102.0, 8: 53.0}   # engine workspace of the sd15 workload per static batch (measured)
 
 
 def parse():
@@ -94,9 +93,7 @@ def cpu_baseline(cfg, weights, n_exec, P, flops_per_image):
         avail = 0
     t0 = time.time()
     if P == 2 and avail < 110e9:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
-        from make_fullsize_loop_fixture import transform_guidance_3stage
-        transform_guidance_3stage(O, args, cfg, models, z, torch.tensor([7]), gts, emb, e0, b0, Pc, Pg)
+        O.transform_guidance_3stage(args, cfg, models, z, torch.tensor([7]), gts, emb, e0, b0, Pc, Pg)
         t_guidance = time.time() - t0 - t_plain
         how = "P=2 chain assembled in three stages (host RAM %.0f GB < 110 GB), the extra no-grad forward subtracted" % (avail / 1e9)
     else:
@@ -127,12 +124,13 @@ def cpu_baseline(cfg, weights, n_exec, P, flops_per_image):
 def cli_rate(eng, cfg, sched, a, B, n_units=128):
     """Output stage at rate (generate_data.py:1221-1234): the drop-in CLI's own loop (`run_expansion`: unit
     packing, sample weights, dd_expand, uint8 quantisation on the GPU, pinned D2H, PNG encoding on the writer threads) over `n_units`
-    synthetic units on the engine the bench just timed, PNGs written to tmpfs.  Writer threads = this rank's share of the host on an
-    8-GPU node (cpu_count // 8, at most 16: the launcher's cap).  Outside the timed region, reported beside `value`."""
+    synthetic units on the engine the bench just timed, PNGs written to tmpfs.  Writer threads = what `generate_data.py --gpus 8` gives
+    each of its ranks on this host (launcher.png_threads(8): the configuration that ships).  Outside the timed region, reported beside `value`."""
     import shutil
     import tempfile
     from distdiff_amd import generate_data as G
-    threads = max(2, min(16, (os.cpu_count() or 8) // 8))
+    from distdiff_amd.launcher import png_threads
+    threads = png_threads(8)
     root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     out = tempfile.mkdtemp(prefix="dd_bench_png_", dir=root)
     old = os.environ.get("DD_PNG_THREADS")
@@ -164,20 +162,25 @@ def agree_batch(B, world, reduce_min):
     return int(reduce_min(B)) if world > 1 else B
 
 
-def timed_steps(step, steps, warmup, barrier, reduce_max, first_step_hooks=None):
+def timed_steps(step, steps, warmup, barrier, reduce_max, profile_hooks=None):
     """The timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; the
-    job's time is the MAX over ranks.  `first_step_hooks` = (before, after) callables around the first timed step (per-op HIP events)."""
+    job's time is the MAX over ranks.  `profile_hooks` = (before, after) callables around the per-op profile pass (HIP events around every
+    op): the LAST warm-up step, so that the timed steps are exactly the product's steps; with no warm-up it is the first timed step."""
     for i in range(warmup):
+        if i == warmup - 1 and profile_hooks:
+            profile_hooks[0]()
         step(i)
+        if i == warmup - 1 and profile_hooks:
+            profile_hooks[1]()
     barrier()
     out = None
     t0 = time.time()
     for i in range(steps):
-        if i == 0 and first_step_hooks:
-            first_step_hooks[0]()
+        if i == 0 and warmup == 0 and profile_hooks:
+            profile_hooks[0]()
         out = step(warmup + i)
-        if i == 0 and first_step_hooks:
-            first_step_hooks[1]()
+        if i == 0 and warmup == 0 and profile_hooks:
+            profile_hooks[1]()
     barrier()
     dt = reduce_max(time.time() - t0)
     return dt, out
@@ -263,8 +266,8 @@ def main():
     B = a.batch
     if B <= 0:
         if a.config == "sd15":
-            free = torch.cuda.mem_get_info(dev)[0]
-            B = 32 if free >= WORKSPACE_GB[32] * 1e9 + 12e9 else 16 if free >= WORKSPACE_GB[16] * 1e9 + 12e9 else 8     # workspace + weights + allocator slack
+            from distdiff_amd.engine import batch_for_free_hbm
+            B = batch_for_free_hbm(torch.cuda.mem_get_info(dev)[0], guided=a.guidance != "none")     # the CLI's own rule
 
             def reduce_min(v):
                 t = torch.tensor([v], device=dev, dtype=torch.int64)
@@ -341,7 +344,7 @@ def main():
 
     def prof_on():
         if not a.no_profile:
-            eng.profile_enable(True)     # HIP events around every op of the first timed step, on the launch stream
+            eng.profile_enable(True)     # HIP events around every op of the profiled step (the last warm-up step), on the launch stream
 
     def prof_off():
         nonlocal prof
@@ -398,6 +401,9 @@ def main():
                                "algorithmic_flops_per_launch": cv["flops"] / max(cv["ops"], 1),
                                "family_ms": {k: v["ms"] for k, v in prof.items()}}
             out["roofline"].update(recorded_traffic(B, a.config))
+        # the metric is on record before the extras run (they drive the PNG writer threads and a CPU oracle: a hang there must not lose it)
+        sys.stderr.write("[bench] measured, extras pending: " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}) + "\n")
+        sys.stderr.flush()
         if world == 1 and not a.no_cli and a.config == "sd15":
             try:
                 out["output_stage"] = cli_rate(eng, cfg, sched, a, B)

@@ -144,6 +144,23 @@ def _stream():
     return vp(torch.cuda.current_stream().cuda_stream)
 
 
+# HBM budget of the 512x512 SD-1.x workload per image of the static batch (measured: 186.7 GB of engine workspace at 32 images with
+# two chained guided steps = 5.83 GB per image; 3.0 GB without guidance) + weights, guide / VAE scratch and allocator slack.  The one
+# place the CLI's and bench.py's automatic batch come from.
+HBM_BYTES_PER_IMAGE_GUIDED = 5.85e9
+HBM_BYTES_PER_IMAGE_PLAIN = 3.0e9
+HBM_BYTES_FIXED = 12e9
+
+
+def batch_for_free_hbm(free_bytes, guided=True):
+    """Largest static engine batch of 32 / 16 / 8 whose workspace fits `free_bytes` of HBM."""
+    per = HBM_BYTES_PER_IMAGE_GUIDED if guided else HBM_BYTES_PER_IMAGE_PLAIN
+    for B in (32, 16):
+        if free_bytes >= B * per + HBM_BYTES_FIXED:
+            return B
+    return 8
+
+
 class Engine:
     """One engine per device. Mirrors the objects the reference builds at generate_data.py:863-922, 1100-1125."""
 

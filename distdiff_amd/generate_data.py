@@ -194,7 +194,9 @@ class AsyncPNGWriter:
     pool, so the next batch's kernels are enqueued while the previous batch is read back and encoded."""
 
     def __init__(self, engine, writer=save_png, threads=None):
-        threads = threads or int(os.environ.get("DD_PNG_THREADS", "4"))    # the launcher caps it by cpu_count // ranks
+        if not threads:      # the launcher sets DD_PNG_THREADS for its ranks; a plain single-process run takes the same function's answer
+            from .launcher import png_threads
+            threads = int(os.environ.get("DD_PNG_THREADS", 0)) or png_threads(int(os.environ.get("WORLD_SIZE", "1")))
         from concurrent.futures import ThreadPoolExecutor
         self.engine, self.writer = engine, writer
         self.pool = ThreadPoolExecutor(max_workers=threads)
@@ -369,16 +371,14 @@ def load_config_and_weights(args, B):
 
 def auto_engine_batch(args, dev, distributed=False):
     """Static engine batch when --engine_batch is not given: 8 for --tiny; at 512x512 the largest of 32 / 16 / 8 whose workspace fits the
-    free HBM (the two activation stashes of the chained guided steps + the liveness-packed gradient slab are ~5.7 GB per image: 187 GB at
-    32 images; 32 images per launch
-    are 4 % faster than 16 on an MI355X); 16 otherwise.  Ranks of one run agree on the minimum."""
+    free HBM (engine.batch_for_free_hbm: the two activation stashes of the chained guided steps + the liveness-packed gradient slab,
+    186.7 GB measured at 32 images; 32 images per launch are 4 % faster than 16 on an MI355X); 16 otherwise.  Ranks of one run agree on the minimum."""
     if args.tiny:
         return 8
     B = 16
     if args.resolution == 512 and torch.device(dev).type == "cuda" and torch.cuda.is_available():
-        per_image = 5.8e9 if args.guidance_type else 3.0e9
-        free = torch.cuda.mem_get_info(torch.device(dev))[0] - 12e9
-        B = 32 if free >= 32 * per_image else 16 if free >= 16 * per_image else 8
+        from .engine import batch_for_free_hbm
+        B = batch_for_free_hbm(torch.cuda.mem_get_info(torch.device(dev))[0], guided=bool(args.guidance_type))
         if distributed:
             import torch.distributed as dist
             t = torch.tensor([B], dtype=torch.int64, device=torch.device(dev))

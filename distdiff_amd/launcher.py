@@ -66,11 +66,20 @@ def kfd_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
     return n
 
 
+PNG_THREADS_MAX = 8      # PNG writer threads of one rank, at most (one thread encodes ~18 512x512 files/s; a rank produces ~16/s)
+
+
+def png_threads(n_ranks=1):
+    """PNG writer threads of one rank when `n_ranks` ranks share this host: its share of the cores, at most PNG_THREADS_MAX.  The ONE
+    place the number comes from: the launcher's environment for its ranks, the CLI's default and bench.py's output-stage extra."""
+    return max(1, min(PNG_THREADS_MAX, (os.cpu_count() or 1) // max(1, n_ranks)))
+
+
 def rank_thread_env(n):
     """Host threads of one rank: N ranks share the node's cores (PNG encoding, torch's intra-op pool), so each gets cpu_count // N
     instead of every rank spawning a pool sized for the whole machine."""
     per = max(1, (os.cpu_count() or 1) // max(1, n))
-    return {"OMP_NUM_THREADS": str(per), "MKL_NUM_THREADS": str(per), "DD_PNG_THREADS": str(max(1, min(4, per)))}
+    return {"OMP_NUM_THREADS": str(per), "MKL_NUM_THREADS": str(per), "DD_PNG_THREADS": str(png_threads(n))}
 
 
 def exit_code(rc):

@@ -550,6 +550,52 @@ def expand_one(args, cfg, models, image_latents, noise, e, b, prompt_embeds, neg
     return z, img, score
 
 
+def transform_guidance_3stage(args, cfg, models, z, targets, gts, emb, e0, b0, Pc, Pg):
+    """transform_guidance (generate_data.py:687-732) for guidance_period = 2 with the chain rule applied per step, so that only ONE
+    step's autograd graph is alive at a time (two chained graphs of the SD-1.5 oracle do not fit 64 GB): the same quantity
+    torch.autograd.grad returns for the reference's loop, checked against the one-graph gradient at the tiny config
+    (tests/golden/make_fullsize_p2_fixture.py).  Returns (new latents, score, (ge, gb))."""
+    import gc
+    unet, vae, guide, sched = models
+    gsz = cfg.guide.input_size
+    t0, t1 = gts
+    P = args.guidance_period
+    assert P == 2 and len(gts) == 2
+
+    def E_of(x0):
+        img = vae.decode(x0 / cfg.vae.scaling_factor)[0]                  # :701
+        gi = F.interpolate(img, size=(gsz, gsz), mode="bicubic")          # :704
+        return energy(args, guide.encode_image(gi).float(), targets, Pc, Pg)
+
+    with torch.no_grad():                                                 # stage 1: first chained step, no graph
+        z0 = z * (1 + e0) + b0                                            # :696
+        z1, _ = denoise_one_step(args, z0, sched, t0, unet, emb)
+    z1r = z1.detach().clone().requires_grad_(True)                        # stage 2: dE2/dz1
+    _, x0_2 = denoise_one_step(args, z1r, sched, t1, unet, emb)
+    E2 = E_of(x0_2)
+    (g_z1,) = torch.autograd.grad(E2, z1r)
+    E2 = E2.detach()
+    del x0_2, z1r
+    gc.collect()
+    e = e0.clone().requires_grad_(True)                                   # stage 3: first step with its graph
+    b = b0.clone().requires_grad_(True)
+    z0 = z * (1 + e) + b
+    z1g, x0_1 = denoise_one_step(args, z0, sched, t0, unet, emb)
+    E1 = E_of(x0_1)
+    total = (E1 + (g_z1 * z1g).sum()) / P                                 # d(E1 + E2)/P through z1
+    ge, gb = torch.autograd.grad(total, [e, b])
+    score = ((E1.detach() + E2) / P)                                      # :719
+    del z1g, x0_1, total
+    gc.collect()
+    e2, b2 = e0 - args.rho * ge, b0 - args.rho * gb                       # :723-724
+    new = z * (1 + e2) + b2
+    lo, hi = z - args.constraint_value, z + args.constraint_value
+    new = torch.where(new < lo, lo, new)                                  # tensor_clamp: lower bound first (:129-132)
+    new = torch.where(new > hi, hi, new)
+    return new.detach(), score, (ge, gb)
+
+
+
 def build_models(cfg, weights):
     guide = {"vit": GuideOracleViT, "mbv2": GuideOracleMBV2}.get(cfg.guide.kind, GuideOracle)(cfg, weights["guide"])
     return (UNetOracle(cfg, weights["unet"]), VAEOracle(cfg, weights["vae"]), guide, DDIMSchedulerOracle(cfg))

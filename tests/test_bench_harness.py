@@ -41,6 +41,7 @@ def _worker(rank, world, port, q):
 
     def step(i):
         calls.append(i)
+        hooks.append(i)
         time.sleep(per_step)
         return (i, B)
 
@@ -72,7 +73,8 @@ def test_bench_multi_rank_arithmetic(world):
     for rank, B, calls, hooks, _, last, images, rate in res:
         assert B == 16                                          # min over ranks
         assert calls == list(range(warmup + steps))             # warm-up steps 0..W-1, timed steps W..W+K-1, nothing else
-        assert hooks == ["on", "off"]                           # per-op profiling brackets the first timed step only
+        # per-op profiling brackets the LAST WARM-UP step only: the timed steps are exactly the product's steps
+        assert hooks == [0, "on", 1, "off", 2, 3, 4, 5], hooks
         assert last == (warmup + steps - 1, 16)
         assert images == steps * 16 * world and abs(rate - images / dt) < 1e-9
 

@@ -204,7 +204,11 @@ def test_gpu_count_without_the_hip_runtime(tmp_path, monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert LA.visible_gpu_count() == 0
     env = LA.rank_thread_env(8)
-    assert int(env["OMP_NUM_THREADS"]) == max(1, (os.cpu_count() or 1) // 8) and 1 <= int(env["DD_PNG_THREADS"]) <= 4
+    assert int(env["OMP_NUM_THREADS"]) == max(1, (os.cpu_count() or 1) // 8)
+    # ONE source of truth for the PNG writer threads: the launcher's environment, the CLI default and bench.py's output-stage extra
+    assert int(env["DD_PNG_THREADS"]) == LA.png_threads(8) and 1 <= LA.png_threads(8) <= LA.PNG_THREADS_MAX
+    import bench, inspect
+    assert "png_threads(8)" in inspect.getsource(bench.cli_rate)
 
 
 def test_spawn_ranks_sets_the_rendezvous_environment(tmp_path):
