@@ -46,7 +46,7 @@ class ConvGemmParams(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("stride", C.c_int),
                 ("shift", C.c_int), ("parity", C.c_int), ("cin", C.c_int), ("ntaps", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ksplit", C.c_int), ("flags", C.c_int),
-                ("alpha", C.c_float), ("force_small", C.c_int)]
+                ("alpha", C.c_float), ("force_small", C.c_int), ("wgroup_rows", C.c_int), ("wgroup_elems", C.c_longlong)]
 
 
 class GroupNormParams(C.Structure):

@@ -383,6 +383,16 @@ hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStrea
   if ((size_t)p.B * p.H * p.W * (size_t)p.x_ld >= 0xFFFF0000ull) return hipErrorInvalidValue;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if ((p.flags & CF_STATS) && (!p.stats || !conv_gemm_can_emit_stats(p, partial_cap_bytes))) return hipErrorInvalidValue;
+  if (p.wgroup_rows > 0) {
+    // grouped weights (a batch of GEMMs stacked along M): the persistent big-tile kernel only, whole tiles per group, no split-K
+    int cfg, split;
+    select_config(p, 0, &cfg, &split);
+    int bm = 0, bn = 0;
+    if (cfg) conv_gemm_big_tile(cfg, &bm, &bn);
+    if (!cfg || split != 1 || p.wgroup_rows % bm || p.ntaps != 1 || (p.flags & ~(CF_OUT_F32 | CF_BIAS))) return hipErrorInvalidValue;
+    p.ksplit = 1;
+    return launch_conv_gemm_big(p, cfg, stream);
+  }
   if (const int tn = conv_halo_config(p)) return launch_conv_halo(p, tn, stream);       // deep 3x3 / stride 1: halo-resident input tile
   if (const int tn = gemm_ws_config(p)) return launch_gemm_ws(p, tn, stream);           // K = 320 pointwise layers: weight-stationary GEMM
   if (const int tn = gemm_pp_config(p)) return launch_gemm_pp(p, tn, stream);           // narrow pointwise layers: ping-pong GEMM

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
   if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
   int l_slot = 0, c_slot = 0;                 // bias ring slots of the loader's / the epilogue's item
   int lw = w_first, l_kt = 0, l_kend = 0;
+  const bf16_t* l_w = p.w;                               // weight matrix of the loader's item (grouped weights: one per row group)
   int l_tap = 0, l_chunk = 0, l_tb = 0;       // fast path: tap / chunk of K-step l_kt and its (prefetched) byte offset
   int pixb[AV], iy0[AV], ix0[AV];             // general path
   unsigned tapmask[AV];                       // fast path: bit t = tap t is inside the image for this row
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
     const int n0 = (tile % ntn) * BN;
     l_kt = kz * per;
     l_kend = min(ksteps, l_kt + per);
+    if (p.wgroup_rows > 0) l_w = p.w + (size_t)(m0 / p.wgroup_rows) * (size_t)p.wgroup_elems;
     {
       const int nb = n0 + lane * 4;
       const unsigned voff = ((p.flags & CF_BIAS) && lane * 4 < BN && nb + 4 <= p.N) ? (unsigned)nb * 4u : OOB;
@@ -290,9 +292,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void conv_gemm
       if (B_HALF && i == BV - 1) {
         // half pass: every wave moves 4 rows with its lanes 0-31 (same DMA count in every wave, so counted vmcnt waits are uniform)
         if (lane < 32)
-          dma16(p.w, smem + buf * BUF_BYTES + BM * 128 + i * (RPT * 128) + wave * 512, wrow[i], wsoff);
+          dma16(l_w, smem + buf * BUF_BYTES + BM * 128 + i * (RPT * 128) + wave * 512, wrow[i], wsoff);
       } else {
-        dma16(p.w, Bbase + i * (RPT * 128), wrow[i], wsoff);
+        dma16(l_w, Bbase + i * (RPT * 128), wrow[i], wsoff);
       }
     }
   };

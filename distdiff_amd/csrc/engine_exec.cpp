@@ -203,7 +203,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = op.q_prescaled ? 0.6931471805599453f : 1.f / sqrtf((float)op.D); p.q_prescaled = op.q_prescaled;
         p.causal = op.causal;
         if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 0) <= c.tmp_cap)
-          HIPCHK(launch_attention_gemm_fwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
+          HIPCHK(launch_attention_gemm_fwd(p, c.scratch_tmp, c.tmp_cap, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
         else
           HIPCHK(launch_attention_fwd(p, c.s));
         if (c.flops) *c.flops += op.flops;
@@ -337,7 +337,7 @@ void run_bwd(const Program& P, const Ctx& c) {
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = op.q_prescaled ? 0.6931471805599453f : 1.f / sqrtf((float)op.D); p.q_prescaled = op.q_prescaled;
         p.d_o = grad_ptr(c, y); p.lddo = y.ld; p.dq = grad_ptr(c, q); p.lddq = q.ld;
         if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 1) <= c.tmp_cap)
-          HIPCHK(launch_attention_gemm_bwd(p, c.scratch_tmp, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
+          HIPCHK(launch_attention_gemm_bwd(p, c.scratch_tmp, c.tmp_cap, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
         else
           HIPCHK(launch_attention_bwd(p, c.s));
         if (c.flops) *c.flops += op.flops * (op.cross_slot >= 0 ? 1.5 : 2.5);

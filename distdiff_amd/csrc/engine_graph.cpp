@@ -87,9 +87,10 @@ struct Builder {
     int y = P.tensor(tq.B, tq.H, tq.W, tq.C);
     Op op; op.kind = OP_ATTN; op.q = q; op.k = k; op.v = v; op.y = y; op.heads = heads; op.D = tq.C / heads; op.Nq = Nq; op.Nk = Nk;
     op.cross_slot = cross_slot; op.causal = causal; op.q_prescaled = q_prescaled;
-    // wide heads (AutoencoderKL mid block) run through GEMMs on a materialised score matrix: per-image scratch (attention_gemm.hip)
+    // wide heads (AutoencoderKL mid block) run through GEMMs on a materialised score matrix: scratch for up to 8 images per launch
+    // (single-head layers: grouped GEMMs over the images, attention_gemm.hip), one image otherwise
     if (op.D >= 256 && cross_slot < 0 && !causal)
-      P.scratch_tmp = std::max(P.scratch_tmp, attention_gemm_workspace(Nq, Nk, op.D, P.want_grad ? 1 : 0));
+      P.scratch_tmp = std::max(P.scratch_tmp, attention_gemm_workspace(Nq, Nk, op.D, P.want_grad ? 1 : 0) * (size_t)(heads == 1 ? std::min(tq.B, 8) : 1));
     op.stats_off = P.fp32_block((size_t)tq.B * heads * Nq * 2);  // lse + delta
     op.flops = 4.0 * tq.B * heads * (double)Nq * Nk * op.D;
     P.ops.push_back(op);

@@ -65,6 +65,9 @@ struct ConvGemmParams {
   int flags;
   float alpha;
   int force_small;      // diagnostics: 1 forces the 128x128-tile kernel
+  int wgroup_rows;      // > 0: GROUPED weights -- output rows [g * wgroup_rows, (g + 1) * wgroup_rows) use the weight matrix at
+  long long wgroup_elems; //   w + g * wgroup_elems (same [N][K] shape each): a batch of independent GEMMs stacked along M in one launch
+                        //   (attention_gemm.hip: S_b = Q_b K_b^T for all images b).  Persistent big-tile kernel only; 0 otherwise.
 };
 
 // Chooses tile configuration / split-K from the shape. `partial_cap_bytes` bounds split-K workspace.
@@ -145,12 +148,13 @@ hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_delta(const AttnParams& p, hipStream_t stream);   // delta[b,h,q] = sum_d dO*O (first stage of the backward)
 // Wide heads (d >= 256: the AutoencoderKL mid-block attention) through the GEMM kernel with a materialised N x N score matrix per image
-// (attention_gemm.hip).  workspace: attention_gemm_workspace() bytes; tap1x1: device int holding the 1x1 tap ((32 << 6) | 32);
+// (attention_gemm.hip).  workspace: at least attention_gemm_workspace() bytes (one image); with more, single-head layers run up to 8
+// images per launch (grouped GEMMs); tap1x1: device int holding the 1x1 tap ((32 << 6) | 32);
 // partial: split-K scratch of launch_conv_gemm.  Same arguments / results as the flash launchers.
 bool attention_gemm_supported(const AttnParams& p);
 size_t attention_gemm_workspace(int Nq, int Nk, int D, int bwd);
-hipError_t launch_attention_gemm_fwd(const AttnParams& p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
-hipError_t launch_attention_gemm_bwd(const AttnParams& p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
+hipError_t launch_attention_gemm_fwd(const AttnParams& p, void* workspace, size_t workspace_bytes, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
+hipError_t launch_attention_gemm_bwd(const AttnParams& p, void* workspace, size_t workspace_bytes, const int* tap1x1, float* partial, size_t partial_cap, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------
 // K6/K7/K9/K10/K12: small HBM-bound kernels.

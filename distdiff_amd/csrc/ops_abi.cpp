@@ -19,11 +19,11 @@ int dd_op_layernorm_bwd(const LayerNormParams* p, void* st) { return (int)launch
 int dd_op_attention_fwd(const AttnParams* p, void* st) { return (int)launch_attention_fwd(*p, S(st)); }
 int dd_op_attention_bwd(const AttnParams* p, void* st) { return (int)launch_attention_bwd(*p, S(st)); }
 size_t dd_op_attention_gemm_workspace(int Nq, int Nk, int D, int bwd) { return attention_gemm_workspace(Nq, Nk, D, bwd); }
-int dd_op_attention_gemm_fwd(const AttnParams* p, void* ws, const int* tap1x1, float* partial, size_t cap, void* st) {
-  return (int)launch_attention_gemm_fwd(*p, ws, tap1x1, partial, cap, S(st));
+int dd_op_attention_gemm_fwd(const AttnParams* p, void* ws, size_t ws_bytes, const int* tap1x1, float* partial, size_t cap, void* st) {
+  return (int)launch_attention_gemm_fwd(*p, ws, ws_bytes, tap1x1, partial, cap, S(st));
 }
-int dd_op_attention_gemm_bwd(const AttnParams* p, void* ws, const int* tap1x1, float* partial, size_t cap, void* st) {
-  return (int)launch_attention_gemm_bwd(*p, ws, tap1x1, partial, cap, S(st));
+int dd_op_attention_gemm_bwd(const AttnParams* p, void* ws, size_t ws_bytes, const int* tap1x1, float* partial, size_t cap, void* st) {
+  return (int)launch_attention_gemm_bwd(*p, ws, ws_bytes, tap1x1, partial, cap, S(st));
 }
 
 int dd_op_conv_f32(const ConvF32Params* p, void* st) { return (int)launch_conv_f32(*p, S(st)); }

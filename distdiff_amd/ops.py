@@ -234,8 +234,9 @@ def layernorm(x, gamma, beta, eps, dy=None, stats=None):
     return dx
 
 
-def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None):
-    """wide-head attention through the GEMM kernel (dd_op_attention_gemm_*): same arguments / results as `attention`."""
+def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, ws_images=8):
+    """wide-head attention through the GEMM kernel (dd_op_attention_gemm_*): same arguments / results as `attention`.  ws_images: scratch
+    for that many images (single-head layers then run min(ws_images, 8, B) images per launch)."""
     L = _lib.lib()
     L.dd_op_attention_gemm_workspace.restype = C.c_size_t
     p = AttnParams()
@@ -244,10 +245,10 @@ def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None):
     p.q, p.k, p.v, p.o, p.lse = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     p.B, p.H, p.Nq, p.Nk, p.D, p.scale = B, H, Nq, Nk, D, scale
-    ws = torch.empty(L.dd_op_attention_gemm_workspace(Nq, Nk, D, 1), device=q.device, dtype=torch.uint8)
+    ws = torch.empty(L.dd_op_attention_gemm_workspace(Nq, Nk, D, 1) * max(1, ws_images), device=q.device, dtype=torch.uint8)
     tap = torch.tensor([(32 << 6) | 32], device=q.device, dtype=torch.int32)
     part = torch.empty(32 * 1024 * 1024, device=q.device, dtype=torch.float32)
-    check(L.dd_op_attention_gemm_fwd(C.byref(p), _ptr(ws), _ptr(tap), _ptr(part), C.c_size_t(part.numel() * 4), _stream()), "attn_gemm_fwd")
+    check(L.dd_op_attention_gemm_fwd(C.byref(p), _ptr(ws), C.c_size_t(ws.numel()), _ptr(tap), _ptr(part), C.c_size_t(part.numel() * 4), _stream()), "attn_gemm_fwd")
     if d_o is None:
         return o, lse
     dq = torch.zeros_like(o)
@@ -256,7 +257,7 @@ def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None):
     delta = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     p.d_o, p.lddo, p.dq, p.lddq, p.delta = _ptr(d_o), d_o.stride(0), _ptr(dq), dq.stride(0), _ptr(delta)
     p.dk, p.dv, p.lddk, p.lddv = _ptr(dk), _ptr(dv), dk.stride(0), dv.stride(0)
-    check(L.dd_op_attention_gemm_bwd(C.byref(p), _ptr(ws), _ptr(tap), _ptr(part), C.c_size_t(part.numel() * 4), _stream()), "attn_gemm_bwd")
+    check(L.dd_op_attention_gemm_bwd(C.byref(p), _ptr(ws), C.c_size_t(ws.numel()), _ptr(tap), _ptr(part), C.c_size_t(part.numel() * 4), _stream()), "attn_gemm_bwd")
     torch.cuda.synchronize()
     return o, lse, dq, dk, dv
 

@@ -46,11 +46,12 @@ int dd_op_layernorm_bwd(const struct LayerNormParams* p, void* stream);
 int dd_op_attention_fwd(const struct AttnParams* p, void* stream);
 int dd_op_attention_bwd(const struct AttnParams* p, void* stream);
 /* wide heads (d >= 256, the AutoencoderKL mid-block attention): the same attention through GEMMs on a materialised N x N score
- * matrix per image.  workspace: dd_op_attention_gemm_workspace() bytes of device scratch; tap1x1: device int = (32 << 6) | 32;
+ * matrix per image.  workspace / workspace_bytes: device scratch of at least dd_op_attention_gemm_workspace() bytes (ONE image); given
+ * k times that, single-head layers run up to min(k, 8) images per launch (grouped GEMMs); tap1x1: device int = (32 << 6) | 32;
  * partial / partial_cap: split-K scratch as for dd_op_conv_gemm. */
 size_t dd_op_attention_gemm_workspace(int Nq, int Nk, int D, int bwd);
-int dd_op_attention_gemm_fwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
-int dd_op_attention_gemm_bwd(const struct AttnParams* p, void* workspace, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
+int dd_op_attention_gemm_fwd(const struct AttnParams* p, void* workspace, size_t workspace_bytes, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
+int dd_op_attention_gemm_bwd(const struct AttnParams* p, void* workspace, size_t workspace_bytes, const int* tap1x1, float* partial, size_t partial_cap, void* stream);
 
 /* fp32 implicit-GEMM convolution / dgrad of the guide network (guide_f32.hip) and its weight packing: w is
  * [Cout][Cin/groups][KH][KW] fp32 (torch grouped layout); out4 = {N, K, cin, ntaps}; wp may be NULL to query sizes */

@@ -575,10 +575,16 @@ def test_attention_4096_keys_peaky_logits(ops, D, H):
     assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what="peaky dV")
 
 
-@pytest.mark.parametrize("case", [("vae_mid_d512", 2, 1, 1024, 1024, 512), ("wide_2heads_d256", 1, 2, 512, 768, 256)], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [("vae_mid_d512", 2, 1, 1024, 1024, 512, 8), ("wide_2heads_d256", 1, 2, 512, 768, 256, 8),
+                                  ("vae_mid_d512_groups_2_2_1", 5, 1, 1024, 1024, 512, 2), ("vae_mid_d512_one_image_scratch", 3, 1, 512, 768, 512, 1),
+                                  ("vae_mid_d512_grouped_launches", 8, 1, 2048, 2048, 512, 8)], ids=lambda c: c[0])
 def test_attention_gemm_path(ops, case):
-    """wide heads through the GEMM kernel (attention_gemm.hip): same contract and tolerances as the flash kernels."""
-    name, B, H, Nq, Nk, D = case
+    """wide heads through the GEMM kernel (attention_gemm.hip): same contract and tolerances as the flash kernels.  Single-head layers run
+    several images per launch (grouped GEMMs: one weight matrix per 256-row-aligned row group of the persistent kernel, batched
+    transposes / softmax): a full group, ragged groups (5 images in groups of 2), one image of scratch, a 768-key case that is not a
+    multiple of 256 rows (stays per image); the 8 x 2048-token case is large enough that every product really is ONE grouped launch
+    (smaller groups fall back to one GEMM per image when the persistent kernel would not fill the chip)."""
+    name, B, H, Nq, Nk, D, ws_images = case
     g = torch.Generator().manual_seed(23)
     q = bf(torch.randn(B, Nq, H, D, generator=g))
     k = bf(torch.randn(B, Nk, H, D, generator=g))
@@ -590,7 +596,7 @@ def test_attention_gemm_path(ops, case):
     d_o = bf(torch.randn(B, Nq, H, D, generator=g))
     gq, gk, gv = torch.autograd.grad(ref, (qr, kr, vr), d_o)
     dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
-    o, lse, dq, dk, dv = ops.attention_gemm(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale, d_o=dev(d_o, Nq))
+    o, lse, dq, dk, dv = ops.attention_gemm(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, scale, d_o=dev(d_o, Nq), ws_images=ws_images)
     torch.cuda.synchronize()
     assert_close(o.reshape(B, Nq, H, D), ref.detach(), rtol=2e-2, atol=2e-3, what=name + " O")
     assert_close(lse, torch.logsumexp(s.detach(), dim=-1), rtol=1e-3, atol=1e-3, what=name + " LSE")
