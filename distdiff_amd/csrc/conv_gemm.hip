@@ -244,18 +244,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvGemmParams p) {
   const size_t total = (size_t)p.M * ngrp;
   const float* bias = p.bias;
   if ((p.flags & CF_BIAS) && p.bias_sel) bias += (size_t)(*p.bias_sel) * p.bias_stride;
+  const bool vec = !(p.N & 3);                             // whole float4 groups: 16-byte loads of the partial slabs
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(idx / ngrp);
     const int ob = (int)(idx % ngrp) * 4;
     int nb, nbg = 0;
     if (geglu) { nb = (ob >> 4) * 32 + (ob & 15); nbg = nb + 16; } else nb = ob;
     float h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-    for (int z = 0; z < p.ksplit; ++z) {
-      const float* pp = p.partial + ((size_t)z * p.M + m) * p.N;
+    if (vec) {
+      for (int z = 0; z < p.ksplit; ++z) {
+        const float* pp = p.partial + ((size_t)z * p.M + m) * p.N;
+        const float4 v = *(const float4*)(pp + nb);
+        h[0] += v.x; h[1] += v.y; h[2] += v.z; h[3] += v.w;
+        if (geglu) { const float4 u = *(const float4*)(pp + nbg); g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w; }
+      }
+    } else {
+      for (int z = 0; z < p.ksplit; ++z) {
+        const float* pp = p.partial + ((size_t)z * p.M + m) * p.N;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (nb + r < p.N) h[r] += pp[nb + r];
-        if (geglu && nbg + r < p.N) g[r] += pp[nbg + r];
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r < p.N) h[r] += pp[nb + r];
+          if (geglu && nbg + r < p.N) g[r] += pp[nbg + r];
+        }
       }
     }
     Epi::apply(p, bias, m, nb, h, g, nbg);
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvGemmParams p) {
 
 int conv_gemm_big_config(int M, int N, int K, int flags);
 int conv_halo_config(const ConvGemmParams& p);           // conv_halo.hip: 0, or the tile form of the halo-resident 3x3 kernel
+int conv_halo_split(const ConvGemmParams& p);            // conv_halo.hip: chunk split of the 8 x 8 level (1: none)
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream);
 int gemm_pp_config(const ConvGemmParams& p);             // conv_halo.hip: pointwise ping-pong GEMM (narrow N)
 hipError_t launch_gemm_pp(const ConvGemmParams& p, int tn, hipStream_t stream);
@@ -307,6 +318,13 @@ static int nonempty_split(int split, int ksteps) {
 
 int conv_gemm_pick_split(int M, int N, int K) {
   int s = small_split(M, N, K);
+  // the chunk split of the halo-resident kernel at the 8 x 8 level (conv_halo_split: it needs geometry this query does not have,
+  // so every small-M 3x3-shaped problem with N % 320 == 0 reserves its scratch)
+  if (M <= 16384 && (M & 255) == 0 && N % 320 == 0 && K % 576 == 0 && K >= 1152) {
+    int hs = 1;
+    while ((M / 256) * (N / 320) * hs < 192 && hs < 16) hs *= 2;
+    if (hs > s) s = hs;
+  }
   for (int flags = 0; flags <= CF_GEGLU; flags += CF_GEGLU) {
     const int cfg = conv_gemm_big_config(M, N, K, flags);
     if (cfg) { const int b = big_split(cfg, M, N, K); if (b > s) s = b; }
@@ -393,7 +411,24 @@ hipError_t launch_conv_gemm(ConvGemmParams p, size_t partial_cap_bytes, hipStrea
     p.ksplit = 1;
     return launch_conv_gemm_big(p, cfg, stream);
   }
-  if (const int tn = conv_halo_config(p)) return launch_conv_halo(p, tn, stream);       // deep 3x3 / stride 1: halo-resident input tile
+  {
+    // deep 3x3 / stride 1: halo-resident input tile; at the 8 x 8 level with a chunk split into the split-K scratch + the reduce kernel
+    ConvGemmParams q = p;
+    const int hs = conv_halo_split(q);
+    if (hs > 1 && (size_t)hs * p.M * p.N * sizeof(float) > partial_cap_bytes) q.partial = nullptr;     // scratch too small: no split form
+    if (const int tn = conv_halo_config(q)) {
+      q.ksplit = conv_halo_split(q) > 1 ? hs : q.ksplit;
+      hipError_t e = launch_conv_halo(q, tn, stream);
+      if (e == hipSuccess && q.ksplit > 1) {
+        const size_t total = (size_t)q.M * ((q.N + 3) / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, q);
+        e = hipGetLastError();
+      }
+      return e;
+    }
+  }
   if (const int tn = gemm_ws_config(p)) return launch_gemm_ws(p, tn, stream);           // K = 320 pointwise layers: weight-stationary GEMM
   if (const int tn = gemm_pp_config(p)) return launch_gemm_pp(p, tn, stream);           // narrow pointwise layers: ping-pong GEMM
   int cfg, split;

@@ -158,11 +158,13 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 // Tile geometry (host: halo_geometry): a tile is th x tw OUTPUT pixels of one image (th * tw = 256, tw = min(Wo, 128) a power of two),
 // i.e. 256 / Wo whole image rows for Wo <= 128 and a 2 x 128 block for wider images; its halo is (th + 2) x (tw + 2) LOGICAL input
 // pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
-struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y; };
+struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y, ipt; };   // ipt: images per tile (4 at 8 x 8: a tile is 4 whole images, each with its own 10 x 10 halo block)
 
 // WN = 4: 256 x (64 TN) tiles, waves 2 (M) x 4 (N); WN = 2: 512 x (32 TN) tiles, waves 4 (M) x 2 (N) -- the narrow outputs of the decoder's
 // last level (N = 128).  Either way a wave owns 128 rows x TN * 16 columns and waves w, w + 4 (one SIMD) sit in different row groups.
-template <int TN, int WN>
+// MI: the 8 x 8 level's form -- multi-image tiles + chunk split with fp32 partial sums; its own instantiation so that the hot forms
+// keep their register allocation (as runtime branches the additions took the TN = 5 kernels from 12 to 80 bytes of scratch).
+template <int TN, int WN, bool MI = false>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, HaloGeo geo) {
   const int lw = geo.ltw, halo_px = geo.halo_px;
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
@@ -191,11 +193,17 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
   const int n0 = (tile % ntn) * BN;
   const int mt = tile / ntn, tpi = geo.tiles_x * geo.tiles_y;
-  const int img = mt / tpi, tin = mt - img * tpi;
+  const int ipt = MI ? geo.ipt : 1;                       // > 1: the tile is ipt whole (8 x 8) images, output rows contiguous
+  const int img = MI ? mt * ipt : mt / tpi, tin = MI ? 0 : mt - img * tpi;
   const int y0 = (tin / geo.tiles_x) * geo.th, x0 = (tin % geo.tiles_x) << lw;    // first output pixel of the tile inside its image
+  const int himg = MI ? (geo.th + 2) * W2 : 0;            // halo pixels of one image of a multi-image tile
+  const int kz = MI ? blockIdx.y : 0;                     // chunk split (8 x 8 level: too few tiles to fill the chip): fp32 partial sums
   const int mimg = img * p.Ho * p.Wo;
   auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };   // output row of tile pixel r
-  const int chunks = p.cin >> 6, KT = chunks * 9;
+  const int chunks_all = p.cin >> 6;
+  const int cper = MI ? (chunks_all + p.ksplit - 1) / (p.ksplit > 0 ? p.ksplit : 1) : chunks_all;
+  const int c_begin = MI ? kz * cper : 0, c_end = MI ? min(chunks_all, c_begin + cper) : chunks_all;
+  const int KT = (c_end - c_begin) * 9;
 
   // ---- per-tap offsets: lane t holds tap t ((dy + 32) << 6 | (dx + 32)); read with readlane where needed
   const int v_taps = lane < 9 ? p.taptab[lane] : 0;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     woff[i] = ((NPC & 7) == 0 || R < BN) ? ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u : OOB;
   }
   auto issue_w = [&](int kt, int i) {
-    if ((NPC & 7) == 0 || wave + 8 * i < NPC) hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)kt * 128u);
+    if ((NPC & 7) == 0 || wave + 8 * i < NPC) hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)(c_begin * 9 + kt) * 128u);
   };
   // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
   const float inv_w2 = 1.f / (float)W2;
@@ -224,11 +232,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     const int npc = (halo_px + 7) >> 3;
     for (int pc = wave; pc < npc; pc += 4) {
       const int hp = pc * 8 + prow;
-      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+      const int hi = MI ? (int)(((float)hp + 0.5f) * (1.f / (float)(himg > 0 ? himg : 1))) : 0;    // image of the tile
+      const int hq = hp - hi * himg;
+      const int hy = (int)(((float)hq + 0.5f) * inv_w2), hx = hq - hy * W2;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;       // logical input pixel (= output pixel coordinates: stride 1, pad 1)
       const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
       const int j = (lane & 7) ^ (hx & 7);
-      const unsigned voff = ok ? ((unsigned)((iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+      const unsigned voff = ok ? ((unsigned)(hi * p.H * p.W + (iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
       hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
     }
   };
@@ -270,8 +280,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue
-  if (gnf) load_coef(0);
-  if (grp == 0) issue_halo(0);
+  if (gnf) load_coef(c_begin);
+  if (grp == 0) issue_halo(c_begin);
 #pragma unroll
   for (int i = 0; i < NWP; ++i) issue_w(0, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,8 +294,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   // two K halves 0.35), TN + 8 fragments live instead of 2 TN + 4.
   bf16x8 wf[TN], xf[8];
   int kt = 0;
-  for (int c = 0; c < chunks; ++c) {
-    if (c > 0) {
+  for (int c = c_begin; c < c_end; ++c) {
+    if (c > c_begin) {
       // every read of the previous chunk's halo has retired (both groups waited lgkmcnt(0) in front of their last X barrier)
       if (grp == 0) {
         if (gnf) load_coef(c);
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
           const int r = wr * 128 + a * 16 + fr;
-          const int hp = r + 2 * (r >> lw) + Wd + 3 + tapoff;            // halo pixel of output pixel r for this tap
+          // halo pixel of output pixel r for this tap (multi-image tiles: + the two border rows of every image in front of r's)
+          const int hp = r + 2 * (r >> lw) + (MI ? 2 * W2 * (r >> 6) : 0) + Wd + 3 + tapoff;
           xf[a] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xs) << 4));
         }
         if (ks == 0 && more) {
@@ -349,6 +360,20 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();           // balance the barrier count of the two groups
 
+  if constexpr (MI) {
+    // chunk split: raw fp32 partial sums [split][M][N]; splitk_reduce_kernel adds them and applies the epilogue
+    constexpr int TNP2 = TN & ~1;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      float* pr = p.partial + ((size_t)kz * p.M + m_of(wr * 128 + a * 16 + fr)) * p.N + n0 + wc * (TN * 16);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int col = jn < TNP2 ? (jn >> 1) * 32 + fq * 8 + (jn & 1) * 4 : jn * 16 + fq * 4;
+        *(float4*)(pr + col) = make_float4(acc[a][jn][0], acc[a][jn][1], acc[a][jn][2], acc[a][jn][3]);
+      }
+    }
+    return;
+  }
   pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s, 0, fr, fq);
 }
 
@@ -561,6 +586,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pps_kernel(ConvGemmParams p) {
 
 bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   const int Wo = p.Wo, Ho = p.Ho;
+  g->ipt = 1;
+  if (Wo == 8 && Ho == 8 && bm == 256 && p.B % 4 == 0 && !p.shift) {
+    // 8 x 8 level: a 256-pixel tile is four whole images, each with its own 10 x 10 halo block
+    g->ltw = 3; g->th = 8; g->halo_px = 4 * 100; g->tiles_x = 1; g->tiles_y = 1; g->ipt = 4;
+    return true;
+  }
   if (Wo < 16 || (Wo & (Wo - 1))) return false;
   const int tw = Wo < 128 ? Wo : 128, th = bm / tw;
   if (Ho % th) return false;
@@ -570,18 +601,31 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   return true;
 }
 
-template <int TN, int WN>
+template <int TN, int WN, bool MI = false>
 hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
   const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
   static int attr = 0;
-  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
+  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
   const int tiles = (p.M / BM) * (p.N / BN);
-  hipLaunchKernelGGL((conv_halo_kernel<TN, WN>), dim3(tiles), dim3(512), lds, stream, p, g);
+  hipLaunchKernelGGL((conv_halo_kernel<TN, WN, MI>), dim3(tiles, MI ? p.ksplit : 1), dim3(512), lds, stream, p, g);
   return hipGetLastError();
 }
 
 }  // namespace
+
+// chunk split of the 8 x 8 level (M = 64 pixels x images: 64 tiles of 256 x 320 at 64 images -- a quarter of the chip): the smallest
+// power of two that gives >= 192 workgroups, every workgroup >= 2 chunks; 1 = this is not that case.  Needs the split-K scratch.
+int conv_halo_split(const ConvGemmParams& p) {
+  static const int on = getenv("DD_HALO_8X8") ? atoi(getenv("DD_HALO_8X8")) : 1;
+  if (!on || p.Wo != 8 || p.Ho != 8 || p.H != 8 || p.W != 8 || p.shift || p.stride != 1 || (p.B & 3) || p.N % 320 || !p.partial) return 1;
+  if (p.flags & ~(CF_BIAS | CF_RES | CF_RELU)) return 1;
+  const int tiles = (p.M / 256) * (p.N / 320), chunks = p.cin >> 6;
+  int s = 1;
+  while (tiles * s < 192 && s < 16) s *= 2;
+  if (s < 2 || chunks / s < 2) return 1;
+  return s;
+}
 
 // 0 = not eligible, else the tile form: 5 = 256 x 320, 4 = 256 x 256, 2 = 512 x 128 (N = 128).  The host reads the tap table once per weight tensor elsewhere: here the
 // caller guarantees a 3x3 / pad 1 table (ntaps == 9 with offsets in {-1, 0, 1}^2), which every packer emits for KH = KW = 3, pad = 1.
@@ -597,7 +641,9 @@ int conv_halo_config(const ConvGemmParams& p) {
   static const int tall = getenv("DD_HALO_TALL") ? atoi(getenv("DD_HALO_TALL")) : 1;
   if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
   if ((size_t)p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;         // byte offsets are per image
-  if (p.ksplit > 1 || p.M != p.B * p.Ho * p.Wo) return 0;
+  if (p.M != p.B * p.Ho * p.Wo) return 0;
+  if (conv_halo_split(p) > 1) return 5;                  // 8 x 8 level: 256 x 320 multi-image tiles + chunk split (fp32 partials)
+  if (p.ksplit > 1) return 0;
   const int forms[4][3] = {{6, 512, 160}, {2, 512, 128}, {5, 256, 320}, {4, 256, 256}};
   for (int f = 0; f < 4; ++f) {
     const int tn = forms[f][0], bm = forms[f][1], bn = forms[f][2];
@@ -660,5 +706,6 @@ extern "C" int dd_debug_read_pp_trace(unsigned long long* host, int n) {
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
   HaloGeo g;
   if (!halo_geometry(p, tn == 2 || tn == 6 ? 512 : 256, &g)) return hipErrorInvalidValue;
+  if (g.ipt > 1) return (tn == 5 && p.ksplit > 1) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
   return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

@@ -164,7 +164,7 @@ class UNetOracle:
         g, eps = u.norm_num_groups, u.norm_eps
         B = sample.shape[0]
         t = torch.as_tensor(timestep).reshape(-1).expand(B)
-        temb = timestep_embedding(t, u.block_out_channels[0], u.flip_sin_to_cos, u.freq_shift)
+        temb = timestep_embedding(t, u.block_out_channels[0], u.flip_sin_to_cos, u.freq_shift).to(sample.dtype)   # diffusers: t_emb.to(dtype=sample.dtype)
         temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
         temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
         if u.add_time_dim:

@@ -14,6 +14,10 @@ its own oracle run.  Stated per quantity (bounds = measured worst row on MI355X 
   final latents   relative L2 vs fp32
   final image     PSNR (peak 1.0), max abs difference, fraction of uint8 bytes that differ / differ by more than 2 levels
   guidance score  relative difference
+
+Bounds are 1.25 x the worst row measured on MI355X with the round-5 binary (the measured values are in the comment of each bound).
+tests/test_fullsize_loop_draws_gpu.py runs the same configs[1] loop on two MORE weight draws (fullsize_loop_w_fixture.pt): an
+independent seed and a moderately non-flat one (attn1.to_q / to_k x 2 in every transformer block: scores x 4).
 """
 import math
 import os
@@ -27,9 +31,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 B = 32
-# bounds (worst row); see the module docstring
-C1 = {"z_rel": 0.03, "psnr": 40.0, "img_max": 0.10, "u8_diff": 0.85, "u8_gt2": 0.25, "score_rel": 0.002}
-C3 = {"z_rel": 0.03, "psnr": 40.0, "img_max": 0.10, "u8_diff": 0.85, "u8_gt2": 0.25, "score_rel": 0.002}
+LOOSE = os.environ.get("DD_LOOP_MEASURE") == "1"      # print the measurements without asserting the bounds (to re-derive them)
+# bounds = 1.25 x the worst row measured on MI355X with the round-5 binary (PSNR: 1.25 x the rms error = -1.94 dB); measured values:
+#   c1  latents 0.0200, PSNR 43.29 dB, max abs 0.0656, u8 bytes differing 0.716 (by > 2 levels 0.1485), score 1.1e-4
+#   c3  latents 0.0136, PSNR 46.28 dB, max abs 0.0312, u8 0.642 (0.0557), score < 1e-5
+C1 = {"z_rel": 0.025, "psnr": 41.3, "img_max": 0.082, "u8_diff": 0.80, "u8_gt2": 0.186, "score_rel": 2.5e-4}
+C3 = {"z_rel": 0.017, "psnr": 44.3, "img_max": 0.039, "u8_diff": 0.75, "u8_gt2": 0.070, "score_rel": 5e-5}
+# the other weight draws (tests/test_fullsize_loop_draws_gpu.py); measured:
+#   s1    latents 0.0171, PSNR 44.05 dB, max abs 0.0436, u8 0.680 (0.1207), score 4e-5
+#   qk14  (scores x 2 in every block, well conditioned)  see below
+#   qk2   (scores x 4 in every block, ILL-conditioned: the oracle's own fp16 / bf16 executions of the tiny loop are 21 % / 27 % from its
+#         fp32 run, tests/test_oracle.py) latents 0.193, PSNR 24.65 dB: error grows by a steady 0.8 % per step (1.1 % after the first step
+#         against 0.73 % for ONE bf16 rounding of the oracle's input); bounded by that reduced-precision family, not a parity claim
+CW = {"s1": {"z_rel": 0.0214, "psnr": 42.1, "img_max": 0.0545, "u8_diff": 0.78, "u8_gt2": 0.151, "score_rel": 1e-4},
+      "qk14": {"z_rel": 0.06, "psnr": 36.0, "img_max": 0.20, "u8_diff": 0.90, "u8_gt2": 0.40, "score_rel": 4e-3},
+      "qk2": {"z_rel": 0.30, "psnr": 21.0, "img_max": 0.50, "u8_diff": 0.97, "u8_gt2": 0.92, "score_rel": 1.5e-3}}
 
 
 def rel(a, b):
@@ -94,12 +110,13 @@ def _compare(tag, w, z, img, scores, bounds):
     print("%s whole loop, B=%d, worst row: final latents rel-L2 %.4f | image PSNR %.2f dB, max abs %.4f, u8 bytes differing %.3f (by > 2 "
           "levels: %.4f) | score rel %.5f" % (tag, len(rows), worst["z_rel"], worst["psnr"], worst["img_max"], worst["u8_diff"],
                                             worst["u8_gt2"], worst["score_rel"]))
-    for r in ("a", "b"):
+    for r in sorted(set(rows)):
         sel = [x for x in per_row if x[0] == r]
         print("   row %s: latents %.4f-%.4f  PSNR %.2f-%.2f" % (r, min(x[1] for x in sel), max(x[1] for x in sel),
                                                                min(x[2] for x in sel), max(x[2] for x in sel)))
-    assert worst["z_rel"] <= bounds["z_rel"] and worst["psnr"] >= bounds["psnr"] and worst["img_max"] <= bounds["img_max"], worst
-    assert worst["u8_diff"] <= bounds["u8_diff"] and worst["u8_gt2"] <= bounds["u8_gt2"] and worst["score_rel"] <= bounds["score_rel"], worst
+    if not LOOSE:
+        assert worst["z_rel"] <= bounds["z_rel"] and worst["psnr"] >= bounds["psnr"] and worst["img_max"] <= bounds["img_max"], (worst, bounds)
+        assert worst["u8_diff"] <= bounds["u8_diff"] and worst["u8_gt2"] <= bounds["u8_gt2"] and worst["score_rel"] <= bounds["score_rel"], (worst, bounds)
     return worst
 
 
@@ -145,3 +162,4 @@ def test_config3_whole_loop_direct_guidance_last_10_steps(world):
     z, img, _ = eng.expand(inp["latents"], inp["noise"], None, None, inp["t196"], si, "direct_guidance", first, cnt)
     scores = eng.image_scores().cpu()
     _compare("c3", w, z, img, scores, C3)
+

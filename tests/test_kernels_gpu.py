@@ -74,6 +74,10 @@ CONV_CASES = [
     ("halo_w256_2x128_tiles", 1, 64, 256, 256, 256, 3, 1, 1, 0),  # images wider than 128: 2 x 128-pixel tiles
     ("halo_w512_up2", 1, 64, 256, 64, 256, 3, 1, 1, 1),           # logical 128 x 512
     ("halo_n128_512x128_tiles", 1, 128, 128, 256, 512, 3, 1, 1, 0),  # N = 128: 512-row tiles (4 x 128 pixels), waves 4 x 2
+    # the 8 x 8 level (M = 64 pixels x images): the halo-resident kernel with four whole images per 256-pixel tile and a split over the
+    # 64-channel chunks into fp32 partial sums + the reduce kernel (4-way at 64 images, 8-way at 32), forward and input-gradient
+    ("halo_8x8_multi_image_split4", 64, 1280, 1280, 8, 8, 3, 1, 1, 0),
+    ("halo_8x8_cin2560_split8", 32, 2560, 1280, 8, 8, 3, 1, 1, 0),
     # N <= 4 (conv_out of the decoder 128 -> 3 and of the UNet 320 -> 4): the small kernel's 256 x 64 tiles
     ("n3_vae_conv_out", 1, 128, 3, 256, 256, 3, 1, 1, 0),
     ("n4_unet_conv_out", 16, 320, 4, 64, 64, 3, 1, 1, 0),
@@ -120,6 +124,25 @@ def test_conv_forward_and_dgrad(ops, case):
         r2 = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w, bias, stride=stride, padding=pad)
         (g2,) = torch.autograd.grad(r2, xr, dy)
         assert_close(ops.from_nhwc(dxs, B, H, W), g2, rtol=2.5e-2, what=name + " dgrad+sumpool")
+
+
+def test_narrow_conv_fp32_output_in_padded_rows(ops):
+    """The decoder's conv_out as the engine calls it: fp32 output into 8-wide rows (only the N valid channels are written), input rows
+    wider than cin (a column view), image borders on all four sides of a non-square image."""
+    g = torch.Generator().manual_seed(31)
+    B, Cin, Cout, H, W = 2, 128, 3, 96, 352
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    xs = torch.zeros((B * H * W, Cin + 64), dtype=torch.bfloat16, device="cuda")
+    xs[:, 64:] = ops.to_nhwc_bf16(x, Cin).cuda()
+    y = torch.full((B * H * W, 8), 7.0, dtype=torch.float32, device="cuda")
+    pk = ops.PackedConv(w, 1, mode=0, bias=bias)
+    ops.conv_gemm(xs[:, 64:], pk, B, H, W, H, W, y=y[:, :Cout], out_f32=True, ksplit=1, x_ld=xs.stride(0))
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(y[:, :Cout], B, H, W), ref, rtol=5e-3, atol=1e-3, what="narrow conv fp32")
+    assert float((y[:, Cout:] - 7.0).abs().max()) == 0.0, "wrote outside the N valid channels"
 
 
 def test_conv_general_staging_path_beyond_4gb(ops):

@@ -231,3 +231,47 @@ def test_guide_gradient_conditioning():
     assert rel(f2, f0) < 1e-2 and rel(g2, g0) > 0.08
     f3, g3 = vjp(x.bfloat16().float())
     assert rel(g3, g0) > 0.02
+
+
+def test_reduced_precision_floor_of_the_oracle_loop():
+    """What the REFERENCE's own dtype costs: the reference runs UNet / VAE / guide in fp16 (generate_data.py:867, :1039), the engine in
+    bf16 (the north_star's dtype: 3 fewer mantissa bits).  The oracle's whole loop (transform guidance P = 2, generate_data.py:1161-1234)
+    at the tiny config with every weight AND activation rounded to fp16, and to bf16, against the fp32 run on the same inputs: the
+    distance between two reduced-precision executions of the same loop is the floor any fp16 / bf16 engine sits on, and puts the
+    engine's full-size numbers (tests/test_fullsize_loop_gpu.py: 44-47 dB, ~70 % of the uint8 bytes differ by one level) in context.
+    Measured: fp16 latents 0.4 %, PSNR 59 dB, 18 % of the bytes differ (0.02 % by more than 2 levels); bf16 latents 3.9 %, PSNR 40 dB,
+    66 % of the bytes differ (27 % by more than 2) -- the engine (bf16 MFMA inputs, fp32 accumulation, fp32 latents / guide / energy)
+    is well inside the all-bf16 execution and between the two."""
+    import math
+    from distdiff_amd.config import tiny_config
+    from distdiff_amd.weights import synthetic_weights
+    cfg = tiny_config(max_batch=1)
+    w = synthetic_weights(cfg, seed=0, num_classes=5)
+    g = torch.Generator().manual_seed(11)
+    L, D = cfg.latent_size, cfg.guide.feature_dim
+    lat, noise = torch.randn(1, 4, L, L, generator=g) * 0.9, torch.randn(1, 4, L, L, generator=g)
+    e, b = torch.rand(1, 4, 1, 1, generator=g), torch.randn(1, 4, 1, 1, generator=g)
+    pos = torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g)
+    neg = torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g)
+    Pc = F.normalize(torch.randn(5, D, generator=g), dim=-1)
+    Pg = F.normalize(torch.randn(5, 3, D, generator=g), dim=-1)
+    args = O.SamplerArgs(guidance_type="transform_guidance", num_inference_steps=10, guidance_step=4, guidance_period=2, strength=0.5,
+                         rho=10.0, constraint_value=0.2)
+
+    def run(dt):
+        ww = {k: {n: (t.to(dt) if t.is_floating_point() else t) for n, t in v.items()} for k, v in w.items()}
+        return O.expand_one(args, cfg, O.build_models(cfg, ww), lat.to(dt), noise.to(dt), e.to(dt), b.to(dt), pos.to(dt), neg.to(dt),
+                            torch.tensor([2]), Pc, Pg)
+
+    z32, i32, s32 = run(torch.float32)
+    u8 = lambda im: im.float().mul(255).add(0.5).clamp(0, 255).to(torch.uint8).int()
+    out = {}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        z, im, s = run(dt)
+        du = (u8(im) - u8(i32)).abs()
+        out[name] = (float((z.float() - z32).norm() / z32.norm()), 10 * math.log10(1.0 / float(((im.float() - i32) ** 2).mean())),
+                     float((du > 0).float().mean()), float((du > 2).float().mean()), abs(float(s) - float(s32)) / abs(float(s32)))
+        print("%s oracle loop vs fp32: latents %.4f, PSNR %.2f dB, u8 bytes differing %.3f (by > 2 levels %.4f), score rel %.2e" % ((name,) + out[name]))
+    assert out["fp16"][0] < 0.01 and out["fp16"][1] > 52.0 and out["fp16"][4] < 1e-4
+    assert out["bf16"][0] < 0.08 and out["bf16"][1] > 35.0 and out["bf16"][4] < 2e-3
+    assert out["fp16"][0] < out["bf16"][0] and out["fp16"][2] < out["bf16"][2]
