@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--schedule_steps", type=int, default=50)
     ap.add_argument("--guidance_step", type=int, default=20)
     ap.add_argument("--guidance_period", type=int, default=2)
+    ap.add_argument("--classes", type=int, default=100, help="classes of the prototype tables (100: Caltech-101-shaped configs[1]; 196: StanfordCars-shaped configs[3])")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--no_cli", action="store_true", help="skip the output-stage extra (the CLI loop + PNG writer on 128 units, outside the timed region)")
@@ -277,7 +278,7 @@ def main():
         else:
             B = (4 if torch.cuda.mem_get_info(dev)[0] >= 175e9 else 2) if a.config == "sdxl" else 16     # sdxl: 161 / 115 GB; 6 is no faster
     cfg = {"sd15": sd15_config, "tiny": tiny_config, "sdxl": sdxl_config}[a.config](max_batch=B)
-    C_cls, K = 100, 3
+    C_cls, K = a.classes, 3
     t_setup = time.time()
     guided = a.guidance != "none"
     # transform guidance chains P guided steps (P activation stashes); a direct-guidance step is differentiated on its own (one)
@@ -378,10 +379,10 @@ def main():
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4] structure: SDXL-base UNet shapes (bf16 attention), " if a.config == "sdxl" else
-                                    "BASELINE configs[1]: SD-1.5 shapes ") +
+                                    ("BASELINE configs[3] (StanfordCars sizes): SD-1.5 shapes " if C_cls == 196 else "BASELINE configs[1]: SD-1.5 shapes ")) +
                                    "%dx%d, %d-step DDIM schedule, strength %.2f (%d executed steps), "
-                                   "CFG 7.5, %s P=%d (class+group prototypes C=100 K=3 D=%d, ResNet-50 guide), final VAE decode"
-                                   % (8 * L, 8 * L, len(ts), a.strength, n_exec, a.guidance, a.guidance_period, D),
+                                   "CFG 7.5, %s P=%d (class+group prototypes C=%d K=3 D=%d, ResNet-50 guide), final VAE decode"
+                                   % (8 * L, 8 * L, len(ts), a.strength, n_exec, a.guidance, a.guidance_period, C_cls, D),
                        "images_per_step_per_gpu": B, "sharding": "image shards per rank (generate_data.py:1003-1007), no data-path collective",
                        "weights": "seeded synthetic, exact SD-1.x / AutoencoderKL / ResNet-50 shapes",
                        "algorithmic_tflop_per_image": flops_per_image / 1e12,
@@ -395,7 +396,7 @@ def main():
         if prof is not None:
             cv = prof["conv_gemm"]
             ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + gemm_pps_kernel + conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + gemm_pps_kernel + gemm_ws_kernel + conv_gemm_big_kernel + conv_gemm_kernel + splitk_reduce_kernel (implicit-GEMM conv/linear fwd+dgrad)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": cv["ops"], "avg_launch_ms": cv["ms"] / max(cv["ops"], 1),
                                "algorithmic_flops_per_launch": cv["flops"] / max(cv["ops"], 1),

@@ -831,6 +831,11 @@ int dd_debug_tensor(dd_engine* E, int prog_inst, int idx, int want_grad, float* 
     const Tn& t = P.t[idx];
     if (info4) { info4[0] = t.rows; info4[1] = t.C; info4[2] = t.ld; info4[3] = t.f32 ? 1 : 0; }
     if (!host_out) return DD_OK;
+    // the gradient slab is packed by liveness: after a run only the pinned ranges (program inputs / outputs, padded tensors) still hold
+    // the tensor's own gradient -- an intermediate's range may have been reused by another tensor since
+    if (want_grad && t.grad && !(t.glo < 0 && t.ghi >= (int)P.ops.size()) && !getenv("DD_NO_GRAD_REUSE"))
+      throw std::runtime_error("gradient of an intermediate tensor: its range of the liveness-packed slab is reused during the reverse run "
+                               "(build the engine with DD_NO_GRAD_REUSE=1 to read it)");
     HIPCHK(hipDeviceSynchronize());
     const dd_engine::Inst& I = E->inst[k];
     char* slab = prog == 0 ? I.unet : prog == 1 ? I.vae : I.guide;

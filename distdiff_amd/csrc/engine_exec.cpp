@@ -1,4 +1,6 @@
 // Execution of a Program: forward and hand-derived reverse runs over the op list (no autograd), op by op on the HIP kernels.
+#include <cstdint>
+#include <string>
 #include "engine_internal.h"
 
 namespace ddi {
@@ -246,10 +248,22 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
   }
 }
 
+// DD_GRAD_CHECK=1: every gradient access of run_bwd is checked against the interval plan_grad_memory packed the slab by
+bool ddi::g_grad_check = getenv("DD_GRAD_CHECK") != nullptr && atoi(getenv("DD_GRAD_CHECK")) != 0;
+static thread_local int t_bwd_op = INT32_MIN;     // op whose backward is running (INT32_MIN: outside run_bwd)
+void ddi::grad_access_check(const Tn& t) {
+  if (t_bwd_op == INT32_MIN) return;
+  if (t_bwd_op < t.glo || t_bwd_op > t.ghi)
+    throw std::runtime_error("gradient plan violated: the backward of op " + std::to_string(t_bwd_op) + " touches a gradient that is only live in [" +
+                             std::to_string(t.glo) + ", " + std::to_string(t.ghi) + "]");
+}
+
 void run_bwd(const Program& P, const Ctx& c) {
   if (c.prof) c.prof->new_run();
+  struct OpScope { ~OpScope() { t_bwd_op = INT32_MIN; } } _scope;
   for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
     const Op& op = P.ops[i];
+    t_bwd_op = i;
     const int fam = (op.kind == OP_CONV && !P.f32) ? Profiler::CONV : op.kind == OP_ATTN ? Profiler::ATTN
                     : (op.kind == OP_GN || op.kind == OP_LN) ? Profiler::NORM : Profiler::OTHER;
     if (c.prof) {

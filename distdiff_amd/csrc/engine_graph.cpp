@@ -312,7 +312,12 @@ void plan_grad_memory(Program& P) {
     placed.push_back({at, size[c], lo[c], hi[c]});
     total = std::max(total, at + size[c]);
   }
-  for (int i = 0; i < nt; ++i) if (P.t[i].grad) P.t[i].goff = newoff[find(i)] + rel[i];
+  for (int i = 0; i < nt; ++i) if (P.t[i].grad) { P.t[i].goff = newoff[find(i)] + rel[i]; P.t[i].glo = lo[find(i)]; P.t[i].ghi = hi[find(i)]; }
+  // consistency of the packing itself: two classes that are alive at the same time never share a byte
+  for (size_t a = 0; a < placed.size(); ++a)
+    for (size_t b = a + 1; b < placed.size(); ++b)
+      if (!(placed[a].hi < placed[b].lo || placed[a].lo > placed[b].hi) && placed[a].off < placed[b].off + placed[b].size && placed[b].off < placed[a].off + placed[a].size)
+        throw std::runtime_error("grad plan: overlapping live ranges");
   if (getenv("DD_PLAN_REPORT")) fprintf(stderr, "[plan] gradient slab: %.3f GB one range per tensor -> %.3f GB by liveness (%zu classes)\n", P.grad_bytes / 1e9, total / 1e9, order.size());
   P.grad_bytes = total;
 }

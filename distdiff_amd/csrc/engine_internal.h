@@ -84,6 +84,11 @@ struct Tn {              // activation tensor or channel view
   // are computed, so the INPUT of a convolution is dead after it ran: GroupNorm / LayerNorm / GEGLU / activation outputs).  It lives in
   // one of two ping-pong buffers shared by all instances instead of the per-instance stash slab.
   bool transient = false; int tr_slot = 0;
+  // Interval of op indices in which the reverse run may touch this tensor's gradient (plan_grad_memory: the interval of its buffer
+  // class; -1 / nops = also outside run_bwd: program inputs / outputs, padded tensors).  Defaults: always.  DD_GRAD_CHECK=1 makes every
+  // gradient access of run_bwd verify it (a fused backward that wrote g(x) outside [producer, last consumer] would corrupt another
+  // tensor's gradient silently once the slab is packed by liveness).
+  int glo = -(1 << 30), ghi = 1 << 30;
 };
 
 enum OpKind { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_CONCAT, OP_MAXPOOL, OP_GAP, OP_ACT, OP_PATCHIFY, OP_VITEMBED, OP_SELECT, OP_DUP };
@@ -219,9 +224,11 @@ struct Ctx {  // per-call execution context
 
 inline char* act_raw(const Ctx& c, const Tn& t) { return t.transient ? c.tr + (size_t)t.tr_slot * c.tr_stride : c.act + t.off; }
 inline bf16_t* act_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)act_raw(c, t); }
-inline bf16_t* grad_ptr(const Ctx& c, const Tn& t) { return (bf16_t*)(c.grad + t.goff); }
+extern bool g_grad_check;                       // DD_GRAD_CHECK=1
+void grad_access_check(const Tn& t);            // throws when run_bwd touches t's gradient outside [t.glo, t.ghi]
+inline bf16_t* grad_ptr(const Ctx& c, const Tn& t) { if (g_grad_check) grad_access_check(t); return (bf16_t*)(c.grad + t.goff); }
 inline float* act_f32(const Ctx& c, const Tn& t) { return (float*)act_raw(c, t); }
-inline float* grad_f32(const Ctx& c, const Tn& t) { return (float*)(c.grad + t.goff); }
+inline float* grad_f32(const Ctx& c, const Tn& t) { if (g_grad_check) grad_access_check(t); return (float*)(c.grad + t.goff); }
 
 }  // namespace ddi
 

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+# The whole suite runs with the gradient-plan validator on (read once when the library is loaded): every gradient access of every reverse
+# program is checked against the live interval the gradient slab was packed by (engine_exec.cpp: grad_access_check).
+os.environ.setdefault("DD_GRAD_CHECK", "1")
 
 
 def pytest_configure(config):

@@ -394,18 +394,24 @@ def test_graph_replay_of_the_plain_step_is_bitwise_identical(hip_lib, fx):
     assert res["0"] == res["1"], res
 
 
-@pytest.mark.parametrize("which", ["tiny", "sd15_256px"])
+@pytest.mark.parametrize("which", ["tiny", "sd15_256px", "tiny_sdxl", "tiny_vit_guide"])
 def test_gradient_slab_by_liveness_is_bitwise_identical(hip_lib, which):
     """plan_grad_memory (engine_graph.cpp): gradient buffers share bytes when their live intervals in the reverse run are disjoint.  The
     guided results -- updated latents, scores, dE/dz0 of the chained transform guidance and of direct guidance -- must be BITWISE those of
     one private range per tensor (DD_NO_GRAD_REUSE=1), twice in a row (stale bytes of a previous run in a shared range must not leak), and
-    the workspace must shrink.  tiny config and SD-1.5 widths at 256x256 (every op kind of the three programs)."""
-    from distdiff_amd.config import sd15_config, tiny_config
+    the workspace must shrink.  tiny config and SD-1.5 widths at 256x256 (every op kind of the three programs), the SDXL structure (per-level
+    transformer depth, nn.Linear proj_in / proj_out, text_time conditioning) and the ViT guide (OP_PATCHIFY / OP_VITEMBED / OP_SELECT /
+    OP_ACT, fp32 image gradient).  tests/conftest.py starts the whole suite with DD_GRAD_CHECK=1: every gradient access of the reverse
+    programs is checked against the interval the slab was packed by (a violation raises out of the guided call)."""
+    from distdiff_amd.config import GuideConfig, sd15_config, tiny_config, tiny_sdxl_config
     from distdiff_amd.engine import Engine
     from distdiff_amd.scheduler import DDIMSchedule
     from distdiff_amd.weights import synthetic_weights
-    cfg = tiny_config(max_batch=2) if which == "tiny" else sd15_config(latent_size=32, max_batch=2)
-    ncls = 5 if which == "tiny" else 100
+    cfg = {"tiny": lambda: tiny_config(max_batch=2), "sd15_256px": lambda: sd15_config(latent_size=32, max_batch=2),
+           "tiny_sdxl": lambda: tiny_sdxl_config(max_batch=2), "tiny_vit_guide": lambda: tiny_config(max_batch=2)}[which]()
+    if which == "tiny_vit_guide":
+        cfg.guide = GuideConfig(kind="vit", input_size=64, vit_width=64, vit_layers=2, vit_heads=2, vit_patch=16, vit_mlp=128, vit_out=32)
+    ncls = 100 if which == "sd15_256px" else 5
     w = synthetic_weights(cfg, seed=0, num_classes=ncls)
     g = torch.Generator().manual_seed(9)
     L, D = cfg.latent_size, cfg.guide.feature_dim
@@ -428,6 +434,9 @@ def test_gradient_slab_by_liveness_is_bitwise_identical(hip_lib, which):
             eng.set_schedule(ts, sched.alphas_cumprod, sched.final_alpha_cumprod, guidance_period=2)
             eng.set_prototypes(Pc, Pg)
             eng.set_prompt(emb.cuda())
+            if cfg.unet.add_time_dim:
+                eng.set_added_cond(torch.randn(4, cfg.unet.add_text_dim, generator=torch.Generator().manual_seed(2)),
+                                   torch.tensor([[128.0, 96.0, 0.0, 8.0, 128.0, 128.0], [64.0, 64.0, 4.0, 0.0, 128.0, 128.0]] * 2))
             eng.set_sample_weights([1.0, 1.0])
             res = []
             for _ in range(2):
