@@ -320,8 +320,20 @@ struct AttnDmaGeo {
 // the first MFMA of every score chain starts from -reference instead of 0 -- so p = exp2(score) needs no fma, and the reference only
 // moves when a tile's maximum exceeds it by more than 2^LZ_SLACK (exact in floating point: the reference cancels in O / l; a tile far
 // above it is rebased before its exponentials).  The row maximum is still computed, but nothing waits for it.
-template <int D, int QT, int KT, int NW, bool LZ>
-__global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(AttnParams p) {
+// FP8 (BASELINE.json configs[4], "fp8 MFMA attention"; AttnParams::pv_fp8, DD_ATTN_FP8=1 in the engine): the P.V product on
+// v_mfma_scale_f32_16x16x128_f8f6f4 -- 128 keys per instruction, e4m3 probabilities x e4m3 values, unit block scales, 2x the bf16 rate per
+// MAC.  d = 64 only (SDXL's head dim), 128-key tiles.  The probabilities leave the softmax as p = exp2(score - reference) with the
+// reference re-based whenever a tile's maximum exceeds it by more than 2^6 (the safe sweep: p <= 64, e4m3 goes to 448), and are packed
+// four keys per dword straight from the score accumulators (keys 16 kt + 4 g + r of lane group g: that IS the instruction's 32-byte
+// operand).  V is quantised when its tile is staged: the bf16 tile arrives by LDS-DMA as before and the workgroup rewrites it as e4m3 in
+// the operand order of the probabilities (row d, lane group g, then (kt, r)), one extra barrier per tile.  QK^T, the softmax, the row
+// sums and the LSE stay as they are (bf16 MFMA, fp32).  tools/micro/pv_fp8.hip measured the UPPER bound of the gain on a register-only
+// loop: 1.18x; with the in-kernel quantisation pass and 90 KB of LDS (one 8-wave workgroup per CU) this form is not faster than the bf16
+// kernel and is not the default.  Accuracy: e4m3 carries 3 mantissa bits (tests/test_kernels_gpu.py states the tolerance).
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+template <int D, int QT, int KT, int NW, bool LZ, bool FP8 = false>
+__global__ __launch_bounds__(NW * 64, FP8 ? 2 : DD_AW_FWD(D)) void attn_fwd_dma_kernel(AttnParams p) {
+  static_assert(!FP8 || (D == 64 && KT == 128 && LZ), "fp8 P.V: d = 64, 128-key tiles, lazy-reference softmax");
   using G = AttnDmaGeo<D>;
   constexpr int DPK = G::DPK, KS = DPK / 32, DVT = (D + 15) / 16, S = G::RB, RG = G::RG, DG = G::DG;
   constexpr int NKT = KT / 16, NC = KT / 32;
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       *(uint4*)(smem + r * S + v * 16) = make_uint4((ONES && isv && v == DG) ? 0x3f80u : 0u, 0, 0, 0);
   }
   if (tid < 8) *(uint4*)(smem + 4 * TILE + tid * 16) = make_uint4(0, 0, 0, 0);
+  unsigned char* const VQ = smem + 4 * TILE + 128;          // FP8: the staged V tile as e4m3, [d 64][lane group 4][32 keys] = 8 KB
 
   bf16x8 qf[QT][KS];
   int qrow[QT];
@@ -416,6 +429,18 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     if (!PARTIAL && k0 + KT < p.Nk && !((DD_ATTN_ABL & 128) && !FIRST)) issue_tile(k0 + KT, buf ^ 1);
     const unsigned char* Ks = smem + buf * 2 * TILE;
     const unsigned char* Vs = Ks + TILE;
+    if constexpr (FP8) {
+      // V tile -> e4m3 in the operand order of the probabilities: dword ((dt * 4 + g) * 16 + i16) * 8 + kt = V[16 kt + 4 g + r][16 dt + i16], r = 0 .. 3
+      // (everybody finished the previous tile's P.V in front of the barrier above; the barrier in front of this tile's P.V publishes it)
+      for (int w = tid; w < 64 * 4 * 8; w += NW * 64) {
+        const int kt = w & 7, d = ((w >> 9) << 4) + ((w >> 3) & 15), gg = (w >> 7) & 3;
+        const unsigned char* src = Vs + (16 * kt + 4 * gg) * S + d * 2;
+        const float f0 = bf2f(*(const bf16_t*)src), f1 = bf2f(*(const bf16_t*)(src + S)), f2 = bf2f(*(const bf16_t*)(src + 2 * S)), f3 = bf2f(*(const bf16_t*)(src + 3 * S));
+        int wv = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+        wv = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, wv, true);
+        *(int*)(VQ + w * 4) = wv;
+      }
+    }
     f32x4 st[QT][NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -429,6 +454,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
       }
     }
     bf16x8 pf[QT][NC];
+    i32x8_t pf8[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       if constexpr (PARTIAL) {                               // only the last tile of a ragged key count needs masking
@@ -455,7 +481,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
         // the tile's row maximum.  Later tiles: the optimistic pass (SAFE = false) exponentiates them as they are -- no row maximum,
         // nothing to wait for -- and the row sums tell at the end whether a row ran away from its reference (see the tail of the
         // kernel); the safe pass rebases a tile more than 2^LZ_SLACK above the reference before its exponentials (wave-uniform, rare).
-        constexpr float LZ_SLACK = 24.f;
+        constexpr float LZ_SLACK = FP8 ? 6.f : 24.f;         // FP8: the probabilities must stay inside e4m3 (448)
         bool rebase = FIRST;
         if constexpr (!FIRST && SAFE) rebase = __any(mx > LZ_SLACK);
         if (rebase) {
@@ -503,8 +529,29 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
         for (int dt = 0; dt < DVT; ++dt) o[qt][dt] *= alpha;
       }
       }
+      if constexpr (FP8) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(st[qt][kt][0], st[qt][kt][1], 0, false);
+          pf8[qt][kt] = __builtin_amdgcn_cvt_pk_fp8_f32(st[qt][kt][2], st[qt][kt][3], lo, true);
+        }
+      } else {
 #pragma unroll
       for (int c = 0; c < NC; ++c) pf[qt][c] = pack_frag(st[qt][2 * c], st[qt][2 * c + 1]);
+      }
+    }
+    if constexpr (FP8) {
+      __syncthreads();                                       // the e4m3 V tile is complete
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt) {
+        const unsigned char* vq = VQ + ((dt * 4 + g) * 16 + i16) * 32;
+        const uint4 v0 = *(const uint4*)vq, v1 = *(const uint4*)(vq + 16);
+        const i32x8_t vf8 = {(int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w, (int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          o[qt][dt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf8, pf8[qt], o[qt][dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+      return;
     }
 #pragma unroll
     for (int dt = 0; dt < DVT; ++dt)
@@ -534,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, DD_AW_FWD(D)) void attn_fwd_dma_kernel(Att
     // away from its first tile's maximum by more than any trained attention does; the workgroup then repeats the sweep with the
     // per-tile maximum and the rebase (the decision is workgroup-uniform: the waves share the K/V ring and its barriers).
     constexpr float LZ_LIMIT = 1.8446744e19f;                // 2^64
-    constexpr bool safe_only = DD_ATTN_SAFE_ONLY;
+    constexpr bool safe_only = DD_ATTN_SAFE_ONLY || FP8;     // FP8: always the per-tile maximum (the probabilities are bounded by 2^LZ_SLACK)
     bool bad = safe_only;
     if (!safe_only) {
       sweep(F_{});
@@ -919,13 +966,13 @@ hipError_t run_fwd2(const AttnParams& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<D, QT, KT, DSPLIT, CAUSAL>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(256), lds, s, p);
   return hipGetLastError();
 }
-template <int D, int QT, int KT, int NW, bool LZ>
+template <int D, int QT, int KT, int NW, bool LZ, bool FP8 = false>
 hipError_t run_fwd_dma2(const AttnParams& p, hipStream_t s) {
   constexpr int QB = NW * QT * 16;
-  constexpr size_t lds = 4 * KT * AttnDmaGeo<D>::RB + 128;
+  constexpr size_t lds = 4 * KT * AttnDmaGeo<D>::RB + 128 + (FP8 ? 8192 : 0);
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<D, QT, KT, NW, LZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QT, KT, NW, LZ>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(NW * 64), lds, s, p);
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<D, QT, KT, NW, LZ, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QT, KT, NW, LZ, FP8>), dim3((p.Nq + QB - 1) / QB, p.H, p.B), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 template <int D, int QT, int KT, int NW>
@@ -1000,7 +1047,17 @@ hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
     // (no key loop, one barrier), 16 queries per wave so that the 6 score tiles fit the register budget.  Built and measured SLOWER on the bench
     // workload (the 16-query waves read the K / V tile twice as often per query): kept behind DD_ATTN_SHORT=1
     case 40: if (attn_short(p)) return run_fwd<40, 1, 96, 1>(p, s); return run_fwd<40, DD_A40_QT, DD_A40_KT, 1>(p, s);
-    case 64: return run_fwd<64, 2, 64, 1>(p, s);
+    case 64:
+      // fp8 P.V (configs[4]): opt-in per launch, non-causal, key / value rows within the LDS-DMA offset range
+      if (p.pv_fp8 && !p.causal && (size_t)p.Nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < 0xF0000000ull)
+        return run_fwd_dma2<64, 2, 128, 8, true, true>(p, s);
+      {
+        // control for the fp8 A/B: the same 8-wave / 128-key tiling with the bf16 P.V (DD_ATTN_D64_WIDE=1, prescaled queries only)
+        static const int wide = getenv("DD_ATTN_D64_WIDE") ? atoi(getenv("DD_ATTN_D64_WIDE")) : 0;
+        if (wide && p.q_prescaled && !p.causal && (size_t)p.Nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < 0xF0000000ull)
+          return run_fwd_dma2<64, 2, 128, 8, true, false>(p, s);
+      }
+      return run_fwd<64, 2, 64, 1>(p, s);
     case 80: if (attn_short(p)) return run_fwd<80, 1, 96, 1>(p, s); return run_fwd<80, 2, 64, 1>(p, s);
     case 160: return run_fwd<160, 2, 64, 1>(p, s);
     case 512: return run_fwd<512, 4, 32, 4>(p, s);   // 64 queries per workgroup: K/V stream traffic per query / 4 (+50 %)

@@ -143,6 +143,7 @@ struct AttnParams {
   float* delta;                             // [B][H][Nq] scratch: rowsum(dO*O)
   int q_prescaled;                          // Q already carries 1/sqrt(D) * log2(e) (folded into the to_q weights): scores are log2-domain; pass scale = ln 2
   int causal;                               // forward only: key j visible to query i iff j <= i (CLIP text encoder)
+  int pv_fp8;                               // forward only, D = 64: P.V on the block-scaled fp8 MFMA (e4m3 probabilities and values)
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);

@@ -262,9 +262,10 @@ def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, ws_images=8):
     return o, lse, dq, dk, dv
 
 
-def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False, q_prescaled=False):
+def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False, q_prescaled=False, pv_fp8=False):
     """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors).  q_prescaled: q already carries
-    1/sqrt(D) * log2(e) (the engine folds it into the to_q weights); pass scale = ln 2 then."""
+    1/sqrt(D) * log2(e) (the engine folds it into the to_q weights); pass scale = ln 2 then.  pv_fp8 (D = 64, forward): the P.V product
+    on the block-scaled fp8 MFMA (e4m3 probabilities and values)."""
     L = _lib.lib()
     p = AttnParams()
     o = torch.zeros((B * Nq, H * D), device=q.device, dtype=torch.bfloat16)
@@ -274,6 +275,7 @@ def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=F
     p.B, p.H, p.Nq, p.Nk, p.D, p.scale = B, H, Nq, Nk, D, scale
     p.causal = 1 if causal else 0
     p.q_prescaled = 1 if q_prescaled else 0
+    p.pv_fp8 = 1 if pv_fp8 else 0
     check(L.dd_op_attention_fwd(C.byref(p), _stream()), "attn_fwd")
     if d_o is None:
         return o, lse
