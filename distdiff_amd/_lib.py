@@ -96,7 +96,7 @@ ENGINE_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
     "dd_set_schedule", "dd_add_noise", "dd_denoise_step", "dd_transform_guidance", "dd_direct_guidance", "dd_decode",
     "dd_expand", "dd_image_to_u8", "dd_guide_encode", "dd_guide_encode_pooled", "dd_unet_forward", "dd_unet_vjp", "dd_decode_vjp", "dd_guide_vjp",
-    "dd_set_prompt", "dd_set_added_cond", "dd_vae_encode", "dd_text_encode", "dd_set_sample_weights", "dd_get_image_scores", "dd_declare_tensor", "dd_packed_bytes", "dd_export_packed", "dd_import_packed", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
+    "dd_set_prompt", "dd_set_added_cond", "dd_vae_encode", "dd_text_encode", "dd_text_encode_tower", "dd_set_sample_weights", "dd_get_image_scores", "dd_declare_tensor", "dd_packed_bytes", "dd_export_packed", "dd_import_packed", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",
 ]
 
 

@@ -8,7 +8,7 @@ overridden from those JSON files when a local model directory is given (SURVEY.m
 import json
 import os
 from dataclasses import asdict, dataclass, field
-from typing import Tuple
+from typing import Optional, Tuple
 
 
 @dataclass
@@ -67,6 +67,7 @@ class TextConfig:
     max_position_embeddings: int = 77
     hidden_act: str = "quick_gelu"
     layer_norm_eps: float = 1e-5
+    projection_dim: int = 0            # second tower only (CLIPTextModelWithProjection): width of text_projection's output
 
 
 @dataclass
@@ -148,6 +149,11 @@ class EngineConfig:
     vae: VAEConfig = field(default_factory=VAEConfig)
     guide: GuideConfig = field(default_factory=GuideConfig)
     text: TextConfig = field(default_factory=TextConfig)
+    # SDXL's text side (diffusers StableDiffusionXLPipeline.encode_prompt): a second tower (text_encoder_2/, CLIPTextModelWithProjection),
+    # both towers read at hidden_states[-2], prompt embedding = cat[text, text2] along the width, pooled embedding = text2's text_embeds
+    text2: Optional[TextConfig] = None
+    text_hidden_layer: int = 0         # 0: last_hidden_state (SD-1.x, dataloader.py:633-646); -2: hidden_states[-2]
+    force_zeros_for_empty_prompt: bool = False    # model_index.json of the SDXL base repo: the empty negative prompt embeds as zeros
     scheduler: SchedulerConfig = field(default_factory=SchedulerConfig)
     latent_size: int = 64              # 512 / 8
     text_len: int = 77
@@ -169,6 +175,11 @@ def sdxl_config(latent_size=128, max_batch=1):
                           num_heads=10, cross_attention_dim=2048, transformer_depth=(1, 2, 10), level_heads=(5, 10, 20),
                           add_time_dim=256, add_text_dim=1280)
     cfg.vae.scaling_factor = 0.13025
+    # text_encoder/ = CLIP ViT-L/14 text tower (the SD-1.x one), text_encoder_2/ = OpenCLIP ViT-bigG/14 text tower
+    cfg.text2 = TextConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20, hidden_act="gelu",
+                           projection_dim=1280)
+    cfg.text_hidden_layer = -2
+    cfg.force_zeros_for_empty_prompt = True
     return cfg
 
 
@@ -177,8 +188,15 @@ def tiny_sdxl_config(latent_size=16, max_batch=2):
     text_time additional conditioning."""
     cfg = tiny_config(latent_size, max_batch)
     cfg.unet = UNetConfig(block_out_channels=(64, 128, 128), layers_per_block=1, down_attn=(False, True, True), up_attn=(True, True, False),
-                          num_heads=2, cross_attention_dim=64, norm_num_groups=8, transformer_depth=(1, 2, 3), level_heads=(2, 2, 4),
+                          num_heads=2, cross_attention_dim=96, norm_num_groups=8, transformer_depth=(1, 2, 3), level_heads=(2, 2, 4),
                           add_time_dim=8, add_text_dim=24)
+    # two text towers whose widths add up to the cross-attention width (32 + 64, head dim 32 like the tiny SD-1.x tower); the second
+    # one projects its pooled token to add_text_dim
+    cfg.text = TextConfig(vocab_size=97, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=1,
+                          max_position_embeddings=13)
+    cfg.text2 = TextConfig(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                           max_position_embeddings=13, hidden_act="gelu", projection_dim=24)
+    cfg.text_hidden_layer = -2
     return cfg
 
 
@@ -240,6 +258,16 @@ def from_model_dir(path, latent_size=64, max_batch=1):
                   "max_position_embeddings", "hidden_act", "layer_norm_eps"):
             if k in t:
                 setattr(cfg.text, k, t[k])
+    t2 = _load("text_encoder_2/config.json")
+    if t2:                                                                  # SDXL layout: two towers, both read at hidden_states[-2]
+        cfg.text2 = TextConfig()
+        for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                  "max_position_embeddings", "hidden_act", "layer_norm_eps", "projection_dim"):
+            if k in t2:
+                setattr(cfg.text2, k, t2[k])
+        cfg.text_hidden_layer = -2
+        mi = _load("model_index.json") or {}
+        cfg.force_zeros_for_empty_prompt = bool(mi.get("force_zeros_for_empty_prompt", True))
     cfg.text_len = cfg.text.max_position_embeddings
     if v and "latent_channels" in v:
         cfg.vae.latent_channels = v["latent_channels"]

@@ -623,6 +623,24 @@ __global__ void vae_sample_kernel(const float* mom, int ld, const float* noise, 
   }
 }
 // bf16 rows [M, ld] -> fp32 rows [M, C]
+// pooled head of transformers' CLIPTextModelWithProjection (SDXL's second text tower): out[n][j] = sum_c x[n T + eos(n)][c] W[j][c] with
+// eos(n) = the FIRST position of the largest token id of prompt n (input_ids.argmax(-1): the eos token is the largest id of the CLIP
+// vocabulary); x = final_layer_norm(last layer) in bf16, W = text_projection.weight [Pd][C] fp32 (no bias).  One wave per output.
+__global__ void clip_pool_project_kernel(const int* ids, const bf16_t* x, int ld, const float* W, float* out, int T, int C, int Pd) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int best = ids[(size_t)n * T], pos = 0;
+  for (int t = 1; t < T; ++t) {
+    const int v = ids[(size_t)n * T + t];
+    if (v > best) { best = v; pos = t; }
+  }
+  const bf16_t* row = x + ((size_t)n * T + pos) * ld;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= Pd) return;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) acc = __builtin_fmaf(bf2f(row[c]), W[(size_t)j * C + c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) out[(size_t)n * Pd + j] = acc;
+}
 __global__ void rows_bf16_to_f32_kernel(const bf16_t* x, int ld, float* y, int M, int C) {
   const size_t total = (size_t)M * C;
   GRID_STRIDE(i, total) { y[i] = bf2f(x[(i / C) * ld + (i % C)]); }
@@ -767,6 +785,10 @@ hipError_t launch_select_rows_bwd(const bf16_t* dy, int ldy, bf16_t* dx, int ldx
 hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
                              float scale, hipStream_t s) {
   LAUNCH(vae_sample_kernel, (size_t)B * C * HW, moments, ld, noise, latents, moments_out, B, C, HW, scale);
+}
+hipError_t launch_clip_pool_project(const int* ids, const bf16_t* x, int ld, const float* W, float* out, int n, int T, int C, int Pd, hipStream_t s) {
+  hipLaunchKernelGGL(clip_pool_project_kernel, dim3((Pd + 3) / 4, n), dim3(256), 0, s, ids, x, ld, W, out, T, C, Pd);
+  return hipGetLastError();
 }
 hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s) {
   LAUNCH(rows_bf16_to_f32_kernel, (size_t)M * C, x, ld, y, M, C);

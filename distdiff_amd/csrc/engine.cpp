@@ -253,7 +253,10 @@ int dd_finalize_weights(dd_engine* E) {
     const bool have_venc = E->has("vae", "encoder.conv_in.weight");
     const bool have_text = E->has("text", "text_model.embeddings.token_embedding.weight");
     if (have_venc) build_vae_encoder(E);
-    if (have_text) build_text_encoder(E);
+    const bool have_text2 = E->has("text2", "text_model.embeddings.token_embedding.weight");
+    if (have_text2 && !have_text) throw std::runtime_error("a second text tower (text2) needs the first one (text)");
+    if (have_text) build_text_encoder(E, 0);
+    if (have_text2) build_text_encoder(E, 1);
     // time embedding MLP weights (fp32, setup-time only)
     auto up = [&](const char* key) {
       const HostTensor& t = E->get("unet", key);
@@ -282,7 +285,7 @@ int dd_finalize_weights(dd_engine* E) {
       I.feat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
       I.gfeat = (float*)E->dmalloc((size_t)B * guide_feat_dim(c) * 4);
     }
-    E->tr_slab = (char*)E->dmalloc(2 * std::max({E->unet.tr_max, E->vae.tr_max, E->guide.tr_max, E->venc.tr_max, E->text.tr_max, (size_t)256}));
+    E->tr_slab = (char*)E->dmalloc(2 * std::max({E->unet.tr_max, E->vae.tr_max, E->guide.tr_max, E->venc.tr_max, E->text.tr_max, E->text2.tr_max, (size_t)256}));
     if (c.enable_grad) {
       // UNet gradients alone; VAE and guide gradients live side by side (bicubic^T bridges them)
       const size_t g = std::max(E->unet.grad_bytes, E->vae.grad_bytes + E->guide.grad_bytes);
@@ -292,10 +295,11 @@ int dd_finalize_weights(dd_engine* E) {
     // encoder programs run before the loop: the image encoder borrows the decoder slab of instance 0 when it fits
     if (have_venc) E->venc_slab = E->venc.act_bytes <= E->vae.act_bytes ? E->inst[0].vae : (char*)E->dmalloc(E->venc.act_bytes);
     if (have_text) E->text_slab = (char*)E->dmalloc(E->text.act_bytes);
+    if (have_text2) E->text2_slab = (char*)E->dmalloc(E->text2.act_bytes);
     E->partial_cap = std::max({E->unet.scratch_partial, E->vae.scratch_partial, E->guide.scratch_partial, E->venc.scratch_partial,
-                               E->text.scratch_partial, (size_t)1 << 20});
+                               E->text.scratch_partial, E->text2.scratch_partial, (size_t)1 << 20});
     E->scratch_partial = (char*)E->dmalloc(E->partial_cap, false);
-    E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, E->venc.scratch_tmp, E->text.scratch_tmp, (size_t)256});
+    E->tmp_cap = std::max({E->unet.scratch_tmp, E->vae.scratch_tmp, E->guide.scratch_tmp, E->venc.scratch_tmp, E->text.scratch_tmp, E->text2.scratch_tmp, (size_t)256});
     if (!getenv("DD_ATTN_FLASH_ONLY")) {   // A/B switch: keep the flash kernels for wide heads too
       const int tap = (32 << 6) | 32;
       E->tap1x1 = (int*)E->dmalloc(sizeof(int), false);
@@ -579,26 +583,42 @@ int dd_vae_encode(dd_engine* E, const float* images, const float* noise, float* 
   });
 }
 
-int dd_text_encode(dd_engine* E, const int* input_ids, float* embeds_out, int n, void* stream) {
-  if (!E || !input_ids || !embeds_out) return DD_ERR_ARG;
+int dd_text_encode_tower(dd_engine* E, int which, const int* input_ids, float* hidden_out, float* pooled_out, int n, void* stream) {
+  if (!E || !input_ids || (!hidden_out && !pooled_out) || which < 0 || which > 1) return DD_ERR_ARG;
   DD_TRY(E, {
     if (!E->finalized) throw std::runtime_error("dd_finalize_weights has not been called");
-    if (!E->text_slab) throw std::runtime_error("no text encoder weights were loaded (text/text_model.* keys)");
+    char* slab = which ? E->text2_slab : E->text_slab;
+    if (!slab) throw std::runtime_error(which ? "no second text tower was loaded (text2/text_model.* keys)" : "no text encoder weights were loaded (text/text_model.* keys)");
     if (n < 1 || n > E->text_batch) throw std::runtime_error("dd_text_encode: n must be in [1, 2*max_batch]");
+    if (pooled_out && (!which || !E->text2_proj_w)) throw std::runtime_error("pooled text embeddings come from the second tower's text_projection (text2/text_projection.weight)");
     const dd_config& c = E->cfg;
     hipStream_t s = (hipStream_t)stream;
-    const int T = c.text_len, Cc = E->text_hidden;
+    Program& P = which ? E->text2 : E->text;
+    const int T = c.text_len, Cc = which ? E->text2_hidden : E->text_hidden;
     HIPCHK(hipMemsetAsync(E->text_ids, 0, (size_t)E->text_batch * T * 4, s));
     HIPCHK(hipMemcpyAsync(E->text_ids, input_ids, (size_t)n * T * 4, hipMemcpyDeviceToDevice, s));
     Run r{E, s, E->text_batch};
-    Ctx ctx = r.ctx(E->text, E->text_slab);
+    Ctx ctx = r.ctx(P, slab);
     ctx.stash = false;
-    const Tn& in = E->text.t[E->text_in];
-    HIPCHK(launch_clip_embed(E->text_ids, E->tok_emb, E->pos_emb, act_ptr(ctx, in), in.ld, in.rows, T, Cc, E->text_vocab, s));
-    run_fwd(E->text, ctx);
-    const Tn& o = E->text.t[E->text_out];
-    HIPCHK(launch_rows_bf16_to_f32(act_ptr(ctx, o), o.ld, embeds_out, n * T, Cc, s));
+    const Tn& in = P.t[which ? E->text2_in : E->text_in];
+    HIPCHK(launch_clip_embed(E->text_ids, which ? E->tok_emb2 : E->tok_emb, which ? E->pos_emb2 : E->pos_emb, act_ptr(ctx, in), in.ld, in.rows, T, Cc,
+                             which ? E->text2_vocab : E->text_vocab, s));
+    run_fwd(P, ctx);
+    if (hidden_out) {
+      const Tn& o = P.t[which ? E->text2_out : E->text_out];
+      HIPCHK(launch_rows_bf16_to_f32(act_ptr(ctx, o), o.ld, hidden_out, n * T, Cc, s));
+    }
+    if (pooled_out) {
+      const Tn& f = P.t[E->text2_final];
+      HIPCHK(launch_clip_pool_project(E->text_ids, act_ptr(ctx, f), f.ld, E->text2_proj_w, pooled_out, n, T, Cc, E->text2_proj, s));
+    }
   });
+}
+
+int dd_text_encode(dd_engine* E, const int* input_ids, float* embeds_out, int n, void* stream) {
+  if (!E || !input_ids || !embeds_out) return DD_ERR_ARG;
+  if (E->text2_slab) { E->err = "this model has two text towers: use dd_text_encode_tower"; return DD_ERR_STATE; }
+  return dd_text_encode_tower(E, 0, input_ids, embeds_out, nullptr, n, stream);
 }
 
 int dd_guide_encode_pooled(dd_engine* E, const float* images, float* feats, int B, int use_max, void* stream);

@@ -631,32 +631,44 @@ void build_vae_encoder(dd_engine* E) {
 
 // f-2: CLIPTextModel (transformers; dataloader.py:633-646 `text_encoder(input_ids)[0]`): token + position embeddings, pre-LN
 // transformer layers with causal self-attention and a quick_gelu (or erf-GELU) MLP, final LayerNorm.  Forward only.
-void build_text_encoder(dd_engine* E) {
+// which = 1: the second tower of an SDXL-style model ("text2", CLIPTextModelWithProjection).  text_hidden_layer = -2: the program output
+// is hidden_states[-2] (the input of the last layer, no final LayerNorm) as StableDiffusionXLPipeline.encode_prompt reads both towers;
+// the second tower also keeps final_layer_norm(last layer) for its pooled head (dd_text_encode_tower).
+void build_text_encoder(dd_engine* E, int which) {
   const dd_config& c = E->cfg;
-  Program& P = E->text;
+  Program& P = which ? E->text2 : E->text;
   P.want_grad = false;
   Builder b(E, P);
-  const std::string m = "text", tm = "text_model.";
+  const std::string m = which ? "text2" : "text", tm = "text_model.";
   const HostTensor& tok = E->get(m, tm + "embeddings.token_embedding.weight");
   const HostTensor& pos = E->get(m, tm + "embeddings.position_embedding.weight");
-  E->text_vocab = (int)tok.shape[0]; E->text_hidden = (int)tok.shape[1];
+  const int vocab = (int)tok.shape[0], C = (int)tok.shape[1];
   if ((int)pos.shape[0] < c.text_len) throw std::runtime_error("text encoder has fewer positions than text_len");
-  if (E->text_hidden != c.unet_cross_dim) throw std::runtime_error("text encoder width != UNet cross_attention_dim");
-  const int heads = c.text_heads > 0 ? c.text_heads : 12;
-  if (E->text_hidden % heads) throw std::runtime_error("text hidden size is not divisible by text_heads");
-  E->tok_emb = (float*)E->wupload(tok.data.data(), tok.numel() * 4);
-  E->pos_emb = (float*)E->wupload(pos.data.data(), pos.numel() * 4);
-  const int Bt = 2 * c.max_batch, T = c.text_len, C = E->text_hidden;
-  const float eps = c.text_eps > 0.f ? c.text_eps : 1e-5f;
-  E->text_batch = Bt;
-  E->text_ids = (int*)E->dmalloc((size_t)Bt * T * 4);
+  const bool two = E->has("text2", tm + "embeddings.token_embedding.weight");
+  if (!two && C != c.unet_cross_dim) throw std::runtime_error("text encoder width != UNet cross_attention_dim");
+  if (c.text_hidden_layer != 0 && c.text_hidden_layer != -2) throw std::runtime_error("text_hidden_layer must be 0 (last_hidden_state) or -2");
+  const int heads = which ? (c.text2_heads > 0 ? c.text2_heads : 20) : (c.text_heads > 0 ? c.text_heads : 12);
+  if (C % heads) throw std::runtime_error("text hidden size is not divisible by its head count");
+  float* te = (float*)E->wupload(tok.data.data(), tok.numel() * 4);
+  float* pe = (float*)E->wupload(pos.data.data(), pos.numel() * 4);
+  const int Bt = 2 * c.max_batch, T = c.text_len;
+  const float eps0 = which ? c.text2_eps : c.text_eps, eps = eps0 > 0.f ? eps0 : 1e-5f;
+  const int act = which ? c.text2_act : c.text_act;
+  if (!E->text_ids) { E->text_batch = Bt; E->text_ids = (int*)E->dmalloc((size_t)Bt * T * 4); }
   int x = P.tensor(Bt, T, 1, C);
-  E->text_in = x;
+  const int in = x;
+  int layers = 0;
   char buf[160];
-  for (int l = 0;; ++l) {
+  for (;; ++layers) {
+    snprintf(buf, sizeof buf, "%sencoder.layers.%d.layer_norm1.weight", tm.c_str(), layers);
+    if (!E->has(m, buf)) break;
+  }
+  if (layers < 2 && c.text_hidden_layer == -2) throw std::runtime_error("text_hidden_layer = -2 needs at least two layers");
+  int penultimate = -1;
+  for (int l = 0; l < layers; ++l) {
+    if (l == layers - 1) penultimate = x;
     snprintf(buf, sizeof buf, "%sencoder.layers.%d", tm.c_str(), l);
     const std::string p = buf;
-    if (!E->has(m, p + ".layer_norm1.weight")) break;
     int h = b.ln(x, make_norm(E, m, p + ".layer_norm1"), eps);
     int qkv = b.conv(h, make_conv_cat(E, m, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, true));
     int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
@@ -664,10 +676,25 @@ void build_text_encoder(dd_engine* E) {
     x = b.conv(o, make_conv(E, m, p + ".self_attn.out_proj", 0), 1, 0, x);
     h = b.ln(x, make_norm(E, m, p + ".layer_norm2"), eps);
     h = b.conv(h, make_conv(E, m, p + ".mlp.fc1", 0));
-    h = b.act(h, c.text_act);
+    h = b.act(h, act);
     x = b.conv(h, make_conv(E, m, p + ".mlp.fc2", 0), 1, 0, x);
   }
-  E->text_out = b.ln(x, make_norm(E, m, tm + "final_layer_norm"), eps, /*keep=*/true);
+  const int fin = b.ln(x, make_norm(E, m, tm + "final_layer_norm"), eps, /*keep=*/true);
+  const int out = c.text_hidden_layer == -2 ? penultimate : fin;
+  if (which) {
+    E->text2_in = in; E->text2_out = out; E->text2_final = fin;
+    E->tok_emb2 = te; E->pos_emb2 = pe; E->text2_vocab = vocab; E->text2_hidden = C;
+    if (E->has(m, "text_projection.weight")) {
+      const HostTensor& pw = E->get(m, "text_projection.weight");
+      if ((int)pw.shape[1] != C) throw std::runtime_error("text2 text_projection width != hidden size");
+      E->text2_proj = (int)pw.shape[0];
+      E->text2_proj_w = (float*)E->wupload(pw.data.data(), pw.numel() * 4);
+    }
+    if (E->text_hidden + C != c.unet_cross_dim) throw std::runtime_error("text + text2 widths != UNet cross_attention_dim");
+  } else {
+    E->text_in = in; E->text_out = out;
+    E->tok_emb = te; E->pos_emb = pe; E->text_vocab = vocab; E->text_hidden = C;
+  }
   check_transients(P);
 }
 

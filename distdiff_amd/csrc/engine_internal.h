@@ -247,11 +247,16 @@ struct dd_engine {
   Program unet, vae, guide;
   int unet_in = -1, unet_out = -1, vae_in = -1, vae_out = -1, guide_in = -1, guide_feat = -1;
   // f-2: the stage before the loop (built when the weights are present)
-  Program venc, text;
+  Program venc, text, text2;
   int venc_in = -1, venc_out = -1, text_in = -1, text_out = -1;
   char* venc_slab = nullptr; char* text_slab = nullptr;
   float* tok_emb = nullptr; float* pos_emb = nullptr; int text_vocab = 0, text_hidden = 0, text_batch = 0;
   int* text_ids = nullptr;
+  // second tower of a two-tower model (SDXL): its own program / slab, plus the pooled head (final LayerNorm output + text_projection)
+  int text2_in = -1, text2_out = -1, text2_final = -1;
+  char* text2_slab = nullptr;
+  float* tok_emb2 = nullptr; float* pos_emb2 = nullptr; int text2_vocab = 0, text2_hidden = 0, text2_proj = 0;
+  float* text2_proj_w = nullptr;                      // [proj][hidden] fp32
   struct CrossSlot { ConvW* wk; ConvW* wv; int C; };
   std::vector<CrossSlot> cross_slots;
   std::vector<std::pair<bf16_t*, bf16_t*>> cross_kv;  // device K,V [2B*text_len, C] per slot
@@ -369,7 +374,7 @@ bool ln_fold_enabled();
 void build_unet(dd_engine* E);
 void build_vae(dd_engine* E);
 void build_vae_encoder(dd_engine* E);
-void build_text_encoder(dd_engine* E);
+void build_text_encoder(dd_engine* E, int which = 0);
 void build_guide(dd_engine* E);
 void build_guide_mbv2(dd_engine* E);
 void build_guide_vit(dd_engine* E);

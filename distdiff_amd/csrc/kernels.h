@@ -259,6 +259,7 @@ hipError_t launch_select_rows_bwd(const bf16_t* dy, int ldy, bf16_t* dx, int ldx
 hipError_t launch_vae_sample(const float* moments, int ld, const float* noise, float* latents, float* moments_out, int B, int C, int HW,
                              float scale, hipStream_t s);
 hipError_t launch_rows_bf16_to_f32(const bf16_t* x, int ld, float* y, int M, int C, hipStream_t s);
+hipError_t launch_clip_pool_project(const int* ids, const bf16_t* x, int ld, const float* W, float* out, int n, int T, int C, int Pd, hipStream_t s);
 
 // ----------------------------------------------------------------------------------------------
 // The guide network in exact fp32 (guide_f32.hip): implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 and the fp32

@@ -56,9 +56,21 @@ def list_stanford_cars(root):
 
 
 def list_generic(root, name):
+    """`<root>/<dataset>/train/<category>/` as the reference's imagenette loader reads it (dataloader.py:317-331).  ImageNet subsets
+    (BASELINE.json configs[4]: ImageNet-100) name their categories by WordNet id: an optional `<root>/<dataset>/classnames.txt`
+    ("<directory name> <class name>" per line, the format of ImageNet's LOC_synset_mapping.txt) supplies the names the prompts use."""
     base = DATASET_PATH.format(root=root, name=name)
     train = os.path.join(base, "train")
-    return _class_dir_listing(train if os.path.isdir(train) else base)
+    paths, labels, cats = _class_dir_listing(train if os.path.isdir(train) else base)
+    mapping = os.path.join(base, "classnames.txt")
+    if os.path.exists(mapping):
+        names = {}
+        for line in open(mapping):
+            parts = line.strip().split(None, 1)
+            if len(parts) == 2:
+                names[parts[0]] = parts[1].split(",")[0].strip()
+        cats = [names.get(c, c) for c in cats]
+    return paths, labels, cats
 
 
 def load_train_listing(name, root="data"):

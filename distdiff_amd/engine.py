@@ -33,6 +33,7 @@ class DDConfig(C.Structure):
         ("guide_kind", C.c_int), ("guide_strides", _IA), ("guide_vit_heads", C.c_int), ("guide_vit_patch", C.c_int), ("guide_vit_act", C.c_int),
         ("guide_feature_dim", C.c_int),
         ("unet_transformer_depth", _IA), ("unet_level_heads", _IA), ("unet_add_time_dim", C.c_int), ("unet_add_text_dim", C.c_int),
+        ("text_hidden_layer", C.c_int), ("text2_heads", C.c_int), ("text2_act", C.c_int), ("text2_eps", C.c_float),
     ]
 
 
@@ -76,6 +77,7 @@ def _declare(l):
     l.dd_guide_encode_pooled.argtypes = [vp, vp, vp, i, i, vp]
     l.dd_vae_encode.argtypes = [vp, vp, vp, vp, vp, i, vp]
     l.dd_text_encode.argtypes = [vp, vp, vp, i, vp]
+    l.dd_text_encode_tower.argtypes = [vp, i, vp, vp, vp, i, vp]
     l.dd_image_to_u8.argtypes = [vp, vp, vp, i, vp]
     l.dd_set_sample_weights.argtypes = [vp, vp, i]
     l.dd_get_image_scores.argtypes = [vp, vp, i, vp]
@@ -133,6 +135,10 @@ def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
     if u.level_heads:
         c.unet_level_heads = arr(u.level_heads)
     c.unet_add_time_dim, c.unet_add_text_dim = u.add_time_dim, u.add_text_dim
+    c.text_hidden_layer = cfg.text_hidden_layer
+    if cfg.text2 is not None:
+        t2 = cfg.text2
+        c.text2_heads, c.text2_act, c.text2_eps = t2.num_attention_heads, {"quick_gelu": 0, "gelu": 1}[t2.hidden_act], t2.layer_norm_eps
     return c
 
 
@@ -165,7 +171,7 @@ class Engine:
     """One engine per device. Mirrors the objects the reference builds at generate_data.py:863-922, 1100-1125."""
 
     def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0", layout=None):
-        """weights: {"unet" | "vae" | "guide" | "text": state dict} -- packed on this rank; or None with `layout` = the
+        """weights: {"unet" | "vae" | "guide" | "text" | "text2": state dict} -- packed on this rank; or None with `layout` = the
         `weight_layout()` of the rank that has them: the engine is then built from the tensor shapes alone and its packed weight
         buffers are filled by `import_packed` (launcher.broadcast_packed_weights: one RCCL broadcast of the packed device buffers
         instead of every process loading its own copy, scripts/exps/expand_diff.sh:19-24)."""
@@ -178,7 +184,7 @@ class Engine:
         self._chk(self.L.dd_create(C.byref(cc), C.byref(self._h)), "dd_create")
         if weights is not None:
             self.layout = []
-            for model in ("unet", "vae", "guide", "text"):
+            for model in ("unet", "vae", "guide", "text", "text2"):
                 for key, t in weights.get(model, {}).items():
                     if key.startswith(("fc.", "classifier.")) or key.endswith("num_batches_tracked"):
                         continue
@@ -296,6 +302,18 @@ class Engine:
         out = torch.empty((n, self.cfg.text_len, self.cfg.unet.cross_attention_dim), device=self.device, dtype=torch.float32)
         self._chk(self.L.dd_text_encode(self._h, _p(ids), _p(out), n, _stream()), "dd_text_encode")
         return out
+
+    def text_encode_tower(self, which, input_ids, pooled=False):
+        """One tower of a two-tower (SDXL) model: ids [n, text_len] of THAT tower's tokenizer -> hidden states [n, text_len, width] at
+        cfg.text_hidden_layer and, for the second tower with pooled=True, text_embeds [n, projection_dim]
+        (CLIPTextModelWithProjection; diffusers StableDiffusionXLPipeline.encode_prompt)."""
+        t = self.cfg.text2 if which else self.cfg.text
+        ids = input_ids.to(self.device, torch.int32).contiguous()
+        n = ids.shape[0]
+        hid = torch.empty((n, self.cfg.text_len, t.hidden_size), device=self.device, dtype=torch.float32)
+        pool = torch.empty((n, t.projection_dim), device=self.device, dtype=torch.float32) if pooled else None
+        self._chk(self.L.dd_text_encode_tower(self._h, int(which), _p(ids), _p(hid), _p(pool), n, _stream()), "dd_text_encode_tower")
+        return (hid, pool) if pooled else hid
 
     # ---- hot path ------------------------------------------------------------------------------
     def _f(self, t):

@@ -92,6 +92,9 @@ def parse_args(argv=None):
     p.add_argument("--synthetic_encode", action="store_true",
                    help="with --synthetic: produce latents / prompt embeddings with the HIP VAE encoder and CLIP text encoder")
     p.add_argument("--tiny", action="store_true", help="use the tiny test architecture (with --synthetic)")
+    p.add_argument("--synthetic_arch", default="sd15", choices=["sd15", "sdxl"],
+                   help="with --synthetic: the SD-1.x structure or the SDXL-base one (two text towers, text_time conditioning; BASELINE "
+                   "configs[4]).  A real model directory is recognised by its text_encoder_2/ sub-folder")
     p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = the largest of 32 / 16 / 8 whose workspace fits the free HBM: 239 / 122 / 65 GB with transform "
                    "guidance at 512x512, 32 being 4 %% faster than 16 and 16 12 %% faster than 8); units (image, expand index) are independent")
     p.add_argument("--data_root", type=str, default="data")
@@ -114,11 +117,13 @@ def parse_args(argv=None):
 # dataset side: the reference's SDDataset.__getitem__ dict (dataloader.py:813-849), from caches or synthetic
 # ------------------------------------------------------------------------------------------------
 class ExpansionDataset:
-    """image_latents [N,4,L,L], per-class text embeds [C,T,Dm], uncond embeds [1,T,Dm], targets, class names, image paths."""
+    """image_latents [N,4,L,L], per-class text embeds [C,T,Dm], uncond embeds [1,T,Dm], targets, class names, image paths; SDXL-style
+    models also carry the pooled text embeddings of the second tower (per class [C,P] and of the negative prompt [1,P])."""
 
-    def __init__(self, latents, class_embeds, uncond_embeds, targets, class_names, image_paths):
+    def __init__(self, latents, class_embeds, uncond_embeds, targets, class_names, image_paths, class_pooled=None, uncond_pooled=None):
         self.latents, self.class_embeds, self.uncond = latents, class_embeds, uncond_embeds
         self.targets, self.class_names, self.image_paths = targets, class_names, image_paths
+        self.class_pooled, self.uncond_pooled = class_pooled, uncond_pooled
 
     def __len__(self):
         return self.latents.shape[0]
@@ -130,10 +135,14 @@ class ExpansionDataset:
         per = math.ceil(n / n_classes)
         targets = torch.tensor([min(i // per, n_classes - 1) for i in range(n)])     # class-sorted like the reference datasets
         names = ["class %d" % c for c in range(n_classes)]
-        return ExpansionDataset(torch.randn(n, 4, L, L, generator=g) * 0.9,
-                                torch.randn(n_classes, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
-                                torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
-                                targets, names, ["%s/image_%04d.jpg" % (names[int(t)], i) for i, t in enumerate(targets)])
+        ds = ExpansionDataset(torch.randn(n, 4, L, L, generator=g) * 0.9,
+                              torch.randn(n_classes, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
+                              torch.randn(1, cfg.text_len, cfg.unet.cross_attention_dim, generator=g),
+                              targets, names, ["%s/image_%04d.jpg" % (names[int(t)], i) for i, t in enumerate(targets)])
+        if cfg.unet.add_time_dim:
+            ds.class_pooled = torch.randn(n_classes, cfg.unet.add_text_dim, generator=g)
+            ds.uncond_pooled = torch.randn(1, cfg.unet.add_text_dim, generator=g)
+        return ds
 
     @staticmethod
     def from_dataset(args, cfg, eng):
@@ -149,6 +158,14 @@ class ExpansionDataset:
         lat = torch.cat([x.float().cpu() for x in lat], dim=0)
         # class prompts + the empty prompt through the HIP CLIP text encoder (dataloader.py:766-786)
         tokenizer = load_tokenizer(args.pretrained_model_name_or_path, args.revision)
+        if cfg.text2 is not None:
+            # SDXL layout: the class prompts go through both towers (tokenizer / tokenizer_2), StableDiffusionXLPipeline.encode_prompt
+            from .preprocess import class_prompt_embeddings_sdxl
+            if args.language_enhance:
+                raise SystemExit("--language_enhance is not built for two-tower (SDXL) models")
+            tokenizer_2 = load_tokenizer(args.pretrained_model_name_or_path, args.revision, subfolder="tokenizer_2")
+            ce, ue, cp, up = class_prompt_embeddings_sdxl(eng, (tokenizer, tokenizer_2), args.dataset, names)
+            return ExpansionDataset(lat, ce, ue, torch.tensor(targets), names, paths, class_pooled=cp, uncond_pooled=up)
         class_embeds, uncond = class_prompt_embeddings(eng, tokenizer, args.dataset, names, language_enhance=args.language_enhance,
                                                        data_root=args.data_root)
         return ExpansionDataset(lat, class_embeds, uncond, torch.tensor(targets), names, paths)
@@ -168,6 +185,12 @@ class ExpansionDataset:
             noise = torch.randn(B, cfg.vae.latent_channels, L, L, generator=g)
             lat.append(eng.vae_encode(x, noise).cpu()[:k])
         ids = torch.randint(0, cfg.text.vocab_size, (n_classes + 1, cfg.text_len), generator=g).int()
+        if cfg.text2 is not None:
+            from .preprocess import encode_token_ids_sdxl
+            ids2 = torch.randint(0, cfg.text2.vocab_size, (n_classes + 1, cfg.text_len), generator=g).int()
+            emb, pooled = encode_token_ids_sdxl(eng, ids, ids2)
+            return ExpansionDataset(torch.cat(lat), emb[:-1], emb[-1:], base.targets, base.class_names, base.image_paths,
+                                    class_pooled=pooled[:-1], uncond_pooled=pooled[-1:])
         emb = encode_token_ids(eng, ids)
         return ExpansionDataset(torch.cat(lat), emb[:-1], emb[-1:], base.targets, base.class_names, base.image_paths)
 
@@ -313,6 +336,12 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
         b = torch.stack([u[5] for u in chunk_p])
         emb = torch.cat([ds.uncond.expand(EB, -1, -1), torch.stack([u[6] for u in chunk_p])])   # cat[negative, prompt], :1184
         engine.set_prompt(emb.to(dev))
+        if ds.class_pooled is not None:
+            # SDXL added_cond_kwargs (StableDiffusionXLPipeline.__call__): pooled text embeddings cat[negative, prompt] and
+            # add_time_ids = (original size, crop top-left, target size), the same for both halves
+            S = float(8 * ds.latents.shape[-1])
+            pooled = torch.cat([ds.uncond_pooled.expand(EB, -1), ds.class_pooled[tg]])
+            engine.set_added_cond(pooled.to(dev), torch.tensor([[S, S, 0.0, 0.0, S, S]]).expand(2 * EB, -1).to(dev))
         if args.guidance_type and hasattr(engine, "set_sample_weights"):
             engine.set_sample_weights([1.0 / u[3] for u in chunk] + [0.0] * (EB - nb))
         z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
@@ -337,12 +366,15 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
 
 def load_config_and_weights(args, B):
     """The model objects the reference builds at generate_data.py:863-922 and :1100-1104, as (EngineConfig, state dicts)."""
-    from .config import GUIDE_ARCHS, from_model_dir, guide_config, sd15_config, tiny_config
+    from .config import GUIDE_ARCHS, from_model_dir, guide_config, sd15_config, sdxl_config, tiny_config, tiny_sdxl_config
     from .model_utils import SUPPORTED, create_model
     from .weights import load_safetensors_dir, synthetic_weights
     latent = args.resolution // 8
     if args.synthetic:
-        cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
+        if args.synthetic_arch == "sdxl":
+            cfg = tiny_sdxl_config(max_batch=B) if args.tiny else sdxl_config(latent, B)
+        else:
+            cfg = tiny_config(max_batch=B) if args.tiny else sd15_config(latent, B)
         if args.arch in GUIDE_ARCHS:                 # -a resnext50 / wideresnet50 / open_clip_vit_b32 (full-size guide only)
             if args.tiny and GUIDE_ARCHS[args.arch].get("kind") == "vit":
                 cfg.guide.kind, cfg.guide.input_size = "vit", 64
@@ -366,6 +398,8 @@ def load_config_and_weights(args, B):
         gsd = {k: v for k, v in gsd.items() if k.startswith("visual.")}
     weights = {"unet": load_safetensors_dir(path, "unet"), "vae": load_safetensors_dir(path, "vae"), "guide": gsd,
                "text": {k: v for k, v in load_safetensors_dir(path, "text_encoder").items() if "position_ids" not in k}}
+    if cfg.text2 is not None:
+        weights["text2"] = {k: v for k, v in load_safetensors_dir(path, "text_encoder_2").items() if "position_ids" not in k}
     return cfg, weights
 
 
@@ -375,6 +409,11 @@ def auto_engine_batch(args, dev, distributed=False):
     186.7 GB measured at 32 images; 32 images per launch are 4 % faster than 16 on an MI355X); 16 otherwise.  Ranks of one run agree on the minimum."""
     if args.tiny:
         return 8
+    if args.synthetic_arch == "sdxl" or os.path.isdir(os.path.join(args.pretrained_model_name_or_path, "text_encoder_2")):
+        # SDXL-base at 1024 x 1024: 161 GB at 4 images, 115 GB at 2 (bench.py --config sdxl)
+        if torch.device(dev).type == "cuda" and torch.cuda.is_available():
+            return 4 if torch.cuda.mem_get_info(torch.device(dev))[0] >= 175e9 else 2
+        return 2
     B = 16
     if args.resolution == 512 and torch.device(dev).type == "cuda" and torch.cuda.is_available():
         from .engine import batch_for_free_hbm

@@ -100,10 +100,11 @@ def load_or_encode_latents(engine, dataset, model_name, image_paths, size, cente
     return latents
 
 
-def load_tokenizer(model_dir, revision=None):
-    """AutoTokenizer.from_pretrained(path, subfolder='tokenizer') as generate_data.py:880-888 (local files only)."""
+def load_tokenizer(model_dir, revision=None, subfolder="tokenizer"):
+    """AutoTokenizer.from_pretrained(path, subfolder='tokenizer') as generate_data.py:880-888 (local files only); SDXL layouts also
+    carry `tokenizer_2` for the second tower."""
     from transformers import CLIPTokenizer
-    return CLIPTokenizer.from_pretrained(model_dir, subfolder="tokenizer", local_files_only=True)
+    return CLIPTokenizer.from_pretrained(model_dir, subfolder=subfolder, local_files_only=True)
 
 
 def tokenize_prompt(tokenizer, prompt, tokenizer_max_length=None):
@@ -122,6 +123,36 @@ def compute_text_embeddings(engine, tokenizer, prompts, tokenizer_max_length=Non
 def encode_token_ids(engine, ids):
     step = 2 * engine.B
     return torch.cat([engine.text_encode(ids[i:i + step]).cpu() for i in range(0, ids.shape[0], step)])
+
+
+def encode_token_ids_sdxl(engine, ids1, ids2):
+    """Both towers of an SDXL-style model (diffusers StableDiffusionXLPipeline.encode_prompt): -> (prompt embeddings
+    [n, text_len, w1 + w2] = cat of the two towers' hidden_states[-2], pooled [n, projection_dim] = the second tower's text_embeds)."""
+    step = 2 * engine.B
+    emb, pooled = [], []
+    for i in range(0, ids1.shape[0], step):
+        h1 = engine.text_encode_tower(0, ids1[i:i + step])
+        h2, p = engine.text_encode_tower(1, ids2[i:i + step], pooled=True)
+        emb.append(torch.cat([h1, h2], dim=-1).cpu())
+        pooled.append(p.cpu())
+    return torch.cat(emb), torch.cat(pooled)
+
+
+def compute_text_embeddings_sdxl(engine, tokenizers, prompts):
+    ids = [torch.cat([tokenize_prompt(tk, p).input_ids for p in prompts]).int() for tk in tokenizers]
+    return encode_token_ids_sdxl(engine, ids[0], ids[1])
+
+
+def class_prompt_embeddings_sdxl(engine, tokenizers, dataset, class_names):
+    """The same class prompts through both towers.  -> (class embeddings [C, T, D], uncond [1, T, D], class pooled [C, P], uncond
+    pooled [1, P]); with `force_zeros_for_empty_prompt` (model_index.json of the SDXL base repo) the empty negative prompt is all
+    zeros, as StableDiffusionXLPipeline.encode_prompt does when no negative prompt is given."""
+    template = CUSTOM_TEMPLATES.get(dataset, "a photo of a {}.")
+    emb, pooled = compute_text_embeddings_sdxl(engine, tokenizers, [template.format(x) for x in class_names] + [""])
+    ue, up = emb[-1:], pooled[-1:]
+    if engine.cfg.force_zeros_for_empty_prompt:
+        ue, up = torch.zeros_like(ue), torch.zeros_like(up)
+    return emb[:-1], ue, pooled[:-1], up
 
 
 def class_prompt_embeddings(engine, tokenizer, dataset, class_names, language_enhance=False, data_root="data"):

@@ -209,13 +209,15 @@ def synthetic_vae_encoder(cfg: EngineConfig, seed=0):
     return b.sd
 
 
-def synthetic_text_encoder(cfg: EngineConfig, seed=0):
-    """transformers CLIPTextModel state-dict keys (text_encoder/ of the SD-1.x repo)."""
-    t = cfg.text
-    b = _Builder("text.", seed)
+def synthetic_text_encoder(cfg: EngineConfig, seed=0, which=0):
+    """transformers CLIPTextModel state-dict keys (text_encoder/ of the SD-1.x repo); which = 1: the second tower of an SDXL-style
+    model (text_encoder_2/, CLIPTextModelWithProjection: the same keys plus `text_projection.weight` [projection_dim, hidden])."""
+    t = cfg.text2 if which else cfg.text
+    pre = "text2." if which else "text."
+    b = _Builder(pre, seed)
     tm = "text_model."
-    b.sd[tm + "embeddings.token_embedding.weight"] = _randn("text.tok", (t.vocab_size, t.hidden_size), 0.5, seed)
-    b.sd[tm + "embeddings.position_embedding.weight"] = _randn("text.pos", (t.max_position_embeddings, t.hidden_size), 0.5, seed)
+    b.sd[tm + "embeddings.token_embedding.weight"] = _randn(pre + "tok", (t.vocab_size, t.hidden_size), 0.5, seed)
+    b.sd[tm + "embeddings.position_embedding.weight"] = _randn(pre + "pos", (t.max_position_embeddings, t.hidden_size), 0.5, seed)
     for l in range(t.num_hidden_layers):
         p = tm + "encoder.layers.%d" % l
         b.norm(p + ".layer_norm1", t.hidden_size)
@@ -225,6 +227,8 @@ def synthetic_text_encoder(cfg: EngineConfig, seed=0):
         b.linear(p + ".mlp.fc1", t.intermediate_size, t.hidden_size)
         b.linear(p + ".mlp.fc2", t.hidden_size, t.intermediate_size)
     b.norm(tm + "final_layer_norm", t.hidden_size)
+    if which:
+        b.sd["text_projection.weight"] = _randn(pre + "proj", (t.projection_dim, t.hidden_size), t.hidden_size ** -0.5, seed)
     return b.sd
 
 
@@ -325,6 +329,8 @@ def synthetic_weights(cfg: EngineConfig, seed=0, num_classes=100, encoders=False
     if encoders:
         w["vae"].update(synthetic_vae_encoder(cfg, seed))
         w["text"] = synthetic_text_encoder(cfg, seed)
+        if cfg.text2 is not None:
+            w["text2"] = synthetic_text_encoder(cfg, seed, which=1)
     return w
 
 

@@ -84,6 +84,13 @@ typedef struct dd_config {
   int unet_transformer_depth[DD_MAX_LEVELS]; /* BasicTransformerBlocks per attention of a level (0: 1) */
   int unet_level_heads[DD_MAX_LEVELS];       /* attention heads of a level (0: unet_num_heads) */
   int unet_add_time_dim, unet_add_text_dim;  /* text_time conditioning: 6 time ids x add_time_dim sinusoids + pooled text embedding */
+  /* SDXL's text side (diffusers StableDiffusionXLPipeline.encode_prompt): two CLIP text towers, "text" (CLIPTextModel) and "text2"
+   * (CLIPTextModelWithProjection, text_encoder_2/config.json), each read at hidden_states[-2]; prompt embedding = cat[text, text2]
+   * along the width (= cross_attention_dim), pooled embedding = text2's text_projection(final_layer_norm(last)[eos]). */
+  int text_hidden_layer;  /* 0: last_hidden_state after final_layer_norm (SD-1.x, dataloader.py:633-646); -2: hidden_states[-2] */
+  int text2_heads;        /* second tower (loaded under model "text2"): num_attention_heads (0: 20) */
+  int text2_act;          /* 0 quick_gelu, 1 gelu (SDXL: gelu) */
+  float text2_eps;        /* layer_norm_eps (0: 1e-5) */
 } dd_config;
 
 typedef struct dd_sampler_params {
@@ -173,6 +180,10 @@ int dd_vae_encode(dd_engine* e, const float* images, const float* noise, float* 
 /* input_ids: DEVICE int32 [n, text_len] (tokenizer output, padded to text_len); embeds_out DEVICE fp32 [n, text_len, cross_dim]
  * = last_hidden_state after final_layer_norm; 1 <= n <= 2*max_batch */
 int dd_text_encode(dd_engine* e, const int* input_ids, float* embeds_out, int n, void* stream);
+/* One tower of a two-tower model (which = 0: "text", 1: "text2"): hidden_out DEVICE fp32 [n, text_len, width of that tower] at
+ * dd_config.text_hidden_layer; pooled_out (which = 1 only, may be NULL) DEVICE fp32 [n, projection_dim] = text_embeds of transformers'
+ * CLIPTextModelWithProjection: text_projection(final_layer_norm(last layer)[position of the largest token id = eos]). */
+int dd_text_encode_tower(dd_engine* e, int which, const int* input_ids, float* hidden_out, float* pooled_out, int n, void* stream);
 /* diagnostic: raw UNet forward, eps2_out DEVICE fp32 [2B,4,L,L] (uncond half first) */
 int dd_unet_forward(dd_engine* e, const float* z, int step_index, float* eps2_out, int B, void* stream);
 

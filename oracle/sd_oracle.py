@@ -276,11 +276,15 @@ def vae_encode(cfg, sd, images, noise=None):
     return z * v.scaling_factor, torch.cat([mean, logvar], 1)
 
 
-def clip_text_encode(cfg, sd, input_ids):
+def clip_text_encode(cfg, sd, input_ids, which=0, hidden_layer=0, pooled=False):
     """transformers CLIPTextModel(input_ids)[0] (dataloader.py:633-646): token + position embeddings, pre-LN layers with
     causal self-attention and quick_gelu / gelu MLP, final LayerNorm.  Pinned against transformers' own CLIPTextModel by
-    tests/golden/make_clip_fixture.py (transformers is importable in the build container)."""
-    t = cfg.text
+    tests/golden/make_clip_fixture.py (transformers is importable in the build container).
+    SDXL's text side (diffusers StableDiffusionXLPipeline.encode_prompt; beyond the reference): which = 1 takes
+    cfg.text2 (CLIPTextModelWithProjection); hidden_layer = -2 returns `hidden_states[-2]` (the input of the last layer, no final
+    LayerNorm); pooled=True also returns `text_embeds` = text_projection(final_layer_norm(last layer)[input_ids.argmax(-1)]).
+    Pinned by the second half of the same fixture."""
+    t = cfg.text2 if which else cfg.text
     tm = "text_model."
     ids = input_ids.long()
     B, T = ids.shape
@@ -288,6 +292,7 @@ def clip_text_encode(cfg, sd, input_ids):
     heads = t.num_attention_heads
     d = t.hidden_size // heads
     mask = torch.full((T, T), float("-inf")).triu(1)
+    hidden = [x]
     for l in range(t.num_hidden_layers):
         p = tm + "encoder.layers.%d" % l
         h = F.layer_norm(x, (t.hidden_size,), sd[p + ".layer_norm1.weight"], sd[p + ".layer_norm1.bias"], t.layer_norm_eps)
@@ -300,7 +305,21 @@ def clip_text_encode(cfg, sd, input_ids):
         h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
         h = h * torch.sigmoid(1.702 * h) if t.hidden_act == "quick_gelu" else F.gelu(h)
         x = x + F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
-    return F.layer_norm(x, (t.hidden_size,), sd[tm + "final_layer_norm.weight"], sd[tm + "final_layer_norm.bias"], t.layer_norm_eps)
+        hidden.append(x)
+    last = F.layer_norm(x, (t.hidden_size,), sd[tm + "final_layer_norm.weight"], sd[tm + "final_layer_norm.bias"], t.layer_norm_eps)
+    out = last if hidden_layer == 0 else hidden[hidden_layer]
+    if not pooled:
+        return out
+    eos = ids.argmax(-1)                          # the eos token is the largest id of the CLIP vocabulary (first occurrence)
+    return out, F.linear(last[torch.arange(B), eos], sd["text_projection.weight"])
+
+
+def sdxl_encode_prompt(cfg, sd1, sd2, ids1, ids2):
+    """diffusers StableDiffusionXLPipeline.encode_prompt for one list of prompts: cat[tower 1, tower 2] of hidden_states[-2] along the
+    width, pooled = tower 2's text_embeds."""
+    h1 = clip_text_encode(cfg, sd1, ids1, which=0, hidden_layer=-2)
+    h2, pooled = clip_text_encode(cfg, sd2, ids2, which=1, hidden_layer=-2, pooled=True)
+    return torch.cat([h1, h2], dim=-1), pooled
 
 
 class ImageProcessorOracle:

@@ -17,12 +17,16 @@ def write_model_dir(root, cfg, w, legacy_vae_names=True, scheduler=None):
     from safetensors.torch import save_file
     u, v, t = cfg.unet, cfg.vae, cfg.text
     os.makedirs(os.path.join(root, "unet"))
-    json.dump({"in_channels": u.in_channels, "out_channels": u.out_channels, "block_out_channels": list(u.block_out_channels),
-               "layers_per_block": u.layers_per_block, "cross_attention_dim": u.cross_attention_dim, "attention_head_dim": u.num_heads,
-               "norm_num_groups": u.norm_num_groups, "norm_eps": u.norm_eps, "freq_shift": 0, "flip_sin_to_cos": True,
-               "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in u.down_attn],
-               "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in u.up_attn]},
-              open(os.path.join(root, "unet", "config.json"), "w"))
+    uc = {"in_channels": u.in_channels, "out_channels": u.out_channels, "block_out_channels": list(u.block_out_channels),
+          "layers_per_block": u.layers_per_block, "cross_attention_dim": u.cross_attention_dim, "attention_head_dim": u.num_heads,
+          "norm_num_groups": u.norm_num_groups, "norm_eps": u.norm_eps, "freq_shift": 0, "flip_sin_to_cos": True,
+          "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in u.down_attn],
+          "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in u.up_attn]}
+    if u.transformer_depth:          # the SDXL-base unet/config.json fields
+        uc.update({"attention_head_dim": list(u.level_heads), "transformer_layers_per_block": list(u.transformer_depth),
+                   "use_linear_projection": True, "addition_embed_type": "text_time", "addition_time_embed_dim": u.add_time_dim,
+                   "projection_class_embeddings_input_dim": u.add_text_dim + 6 * u.add_time_dim})
+    json.dump(uc, open(os.path.join(root, "unet", "config.json"), "w"))
     save_file({k: x.contiguous() for k, x in w["unet"].items()}, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
     os.makedirs(os.path.join(root, "vae"))
     json.dump({"latent_channels": v.latent_channels, "block_out_channels": list(v.block_out_channels), "layers_per_block": v.layers_per_block,
@@ -44,11 +48,40 @@ def write_model_dir(root, cfg, w, legacy_vae_names=True, scheduler=None):
     txt = {k: x.contiguous() for k, x in w["text"].items()}
     txt["text_model.embeddings.position_ids"] = torch.arange(t.max_position_embeddings)[None].float()    # present in real checkpoints
     save_file(txt, os.path.join(root, "text_encoder", "model.safetensors"))
+    if cfg.text2 is not None:       # SDXL layout: text_encoder_2/ (CLIPTextModelWithProjection) + model_index.json
+        t2 = cfg.text2
+        os.makedirs(os.path.join(root, "text_encoder_2"))
+        json.dump({"architectures": ["CLIPTextModelWithProjection"], "vocab_size": t2.vocab_size, "hidden_size": t2.hidden_size,
+                   "intermediate_size": t2.intermediate_size, "num_hidden_layers": t2.num_hidden_layers,
+                   "num_attention_heads": t2.num_attention_heads, "max_position_embeddings": t2.max_position_embeddings,
+                   "hidden_act": t2.hidden_act, "layer_norm_eps": t2.layer_norm_eps, "projection_dim": t2.projection_dim,
+                   "eos_token_id": 2}, open(os.path.join(root, "text_encoder_2", "config.json"), "w"))
+        save_file({k: x.contiguous() for k, x in w["text2"].items()}, os.path.join(root, "text_encoder_2", "model.safetensors"))
+        json.dump({"_class_name": "StableDiffusionXLPipeline", "force_zeros_for_empty_prompt": True},
+                  open(os.path.join(root, "model_index.json"), "w"))
     os.makedirs(os.path.join(root, "scheduler"))
     sc = {"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear", "steps_offset": 1,
           "set_alpha_to_one": False, "clip_sample": False, "prediction_type": "epsilon", "timestep_spacing": "leading"}
     sc.update(scheduler or {})
     json.dump(sc, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+
+
+def test_sdxl_model_dir_round_trip(tmp_path):
+    """The SDXL-base layout (unet config with per-level heads / transformer depths / text_time conditioning, text_encoder_2/,
+    model_index.json) -> from_model_dir reproduces the config the weights were made for."""
+    from distdiff_amd.config import tiny_sdxl_config
+    cfg = tiny_sdxl_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=5, encoders=True)
+    root = str(tmp_path / "sdxl-tiny")
+    write_model_dir(root, cfg, w)
+    got = from_model_dir(root, cfg.latent_size, 2)
+    import dataclasses
+    # (num_heads is not read when per-level head counts are given: the mid block takes the last level's)
+    assert dataclasses.replace(got.unet, num_heads=cfg.unet.num_heads) == cfg.unet and got.text == cfg.text and got.text2 == cfg.text2
+    assert got.text_hidden_layer == -2 and got.force_zeros_for_empty_prompt
+    from distdiff_amd.weights import load_safetensors_dir
+    sd = load_safetensors_dir(root, "text_encoder_2")
+    assert torch.equal(sd["text_projection.weight"], w["text2"]["text_projection.weight"])
 
 
 def test_model_dir_round_trip(tmp_path):

@@ -41,6 +41,18 @@ def test_cli_synthetic_encode_runs_both_encoders(hip_lib, tmp_path):
     assert len(files) == 12
 
 
+def test_cli_sdxl_structure_synthetic(hip_lib, tmp_path):
+    """--synthetic_arch sdxl (BASELINE configs[4] structure at test size): the CLI drives the SDXL UNet with its text_time conditioning --
+    pooled text embeddings + add_time_ids through dd_set_added_cond per engine batch (the engine refuses to step without them) -- first
+    from seeded embeddings, then with --synthetic_encode from BOTH text towers (hidden_states[-2] of each, pooled text_embeds)."""
+    out = _run(tmp_path, 0, 1, extra=["--synthetic_arch", "sdxl"])
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
+    assert len(files) == 12
+    out = _run(tmp_path / "enc", 0, 1, extra=["--synthetic_arch", "sdxl", "--synthetic_encode"])
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
+    assert len(files) == 12
+
+
 def test_latent_cache_format_and_reuse(hip_lib, tmp_path):
     """dataloader.py:788-811: images on disk -> list of [1,4,L,L] latents saved to image_latents.pt; a second call loads the file."""
     import numpy as np
@@ -209,3 +221,47 @@ def test_cli_on_a_model_directory_and_image_files(hip_lib, tmp_path, monkeypatch
     os.remove(files[3])
     assert G.main(argv) == 0                                 # resume: only the missing (batch, expand index) group is regenerated
     assert os.path.exists(files[3]) and all(os.path.getmtime(f) == mt[f] for f in files if f != files[3])
+
+
+def test_cli_on_an_sdxl_model_directory(hip_lib, tmp_path, monkeypatch):
+    """The SDXL layout through the non-synthetic product path: unet/config.json with per-level heads, transformer depths and text_time
+    conditioning, text_encoder/ + text_encoder_2/ (with text_projection), tokenizer/ + tokenizer_2/, model_index.json; a class tree whose
+    directories are WordNet-style ids named by classnames.txt (ImageNet subsets, BASELINE configs[4]).  The class prompts go through both
+    tokenizers and both HIP towers; pooled embeddings and time ids reach the UNet; PNGs come out under the mapped class names."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distdiff_amd import generate_data as G
+    from distdiff_amd.config import guide_config, sd15_config, tiny_sdxl_config
+    from distdiff_amd.weights import synthetic_guide, synthetic_weights
+    from test_checkpoints import write_model_dir
+    monkeypatch.chdir(tmp_path)
+    model = str(tmp_path / "sdxl-tiny")
+    cfg = tiny_sdxl_config(max_batch=4)
+    V = _write_tokenizer(os.path.join(model, "tokenizer"))
+    V2 = _write_tokenizer(os.path.join(model, "tokenizer_2"))
+    cfg.text.vocab_size, cfg.text2.vocab_size = V, V2
+    write_model_dir(model, cfg, synthetic_weights(cfg, seed=0, num_classes=2, encoders=True))
+    gcfg = sd15_config()
+    gcfg.guide = guide_config("resnet50")
+    ck = str(tmp_path / "model_best.pth.tar")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in synthetic_guide(gcfg, seed=1, num_classes=2).items()}, "acc": 0,
+                "best_acc": 0, "optimizer": {}}, ck)
+    rng = np.random.RandomState(0)
+    for c in ("n01440764", "n01443537"):
+        d = tmp_path / "data" / "imagenet100" / "train" / c
+        d.mkdir(parents=True)
+        for i in range(2):
+            Image.fromarray(rng.randint(0, 255, (150 + 10 * i, 140 + 20 * i, 3), dtype=np.uint8)).save(str(d / ("im%d.jpg" % i)), quality=90)
+    open(str(tmp_path / "data" / "imagenet100" / "classnames.txt"), "w").write("n01440764 tench, Tinca tinca\nn01443537 goldfish, Carassius auratus\n")
+    out = str(tmp_path / "out")
+    argv = ["--pretrained_model_name_or_path", model, "-d", "imagenet100", "-a", "resnet50", "--encoder_weight_path", ck, "--data_root",
+            str(tmp_path / "data"), "--output_dir", out, "--resolution", "128", "--steps", "10", "--strength", "0.5", "--guidance_type",
+            "transform_guidance", "--guidance_step", "4", "--guidance_period", "2", "--optimize_targets", "global_prototype-local_prototype",
+            "--K", "2", "--train_batch_size", "1", "--engine_batch", "4", "--num_images_per_prompt", "2", "--constraint_value", "0.2",
+            "--total_split", "1", "--split", "0"]
+    assert G.main(argv) == 0
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs)
+    assert len(files) == 8 and sorted({os.path.basename(os.path.dirname(f)) for f in files}) == ["goldfish", "tench"]
+    im = np.asarray(Image.open(files[0]))
+    assert im.shape == (128, 128, 3) and im.std() > 1.0

@@ -51,6 +51,39 @@ def test_text_encoder_vs_transformers_fixture_and_oracle(hip_lib, act):
         eng.close()
 
 
+def test_sdxl_text_towers_vs_transformers_fixture_and_oracle(hip_lib):
+    """SDXL's text side: both towers of the tiny SDXL config through dd_text_encode_tower -- hidden_states[-2] of each
+    and the second tower's pooled text_embeds -- against the vectors recorded from transformers' CLIPTextModel /
+    CLIPTextModelWithProjection (clip_fixture_sdxl.pt) and the oracle; bf16 storage: 3 %."""
+    from distdiff_amd.config import tiny_sdxl_config
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    cfg = tiny_sdxl_config(max_batch=2)
+    w = synthetic_weights(cfg, seed=0, num_classes=5, encoders=True)
+    assert "text2" in w and "text_projection.weight" in w["text2"]
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "clip_fixture_sdxl.pt"), weights_only=False)["towers"]
+    eng = _engine(cfg, w)
+    try:
+        h1 = eng.text_encode_tower(0, fx[0]["input_ids"])
+        h2, pooled = eng.text_encode_tower(1, fx[1]["input_ids"], pooled=True)
+        assert h1.shape == (4, cfg.text_len, cfg.text.hidden_size) and h2.shape == (4, cfg.text_len, cfg.text2.hidden_size)
+        assert pooled.shape == (4, cfg.unet.add_text_dim)
+        assert rel(h1, fx[0]["hidden_m2"]) < 0.03 and rel(h2, fx[1]["hidden_m2"]) < 0.03
+        assert rel(pooled, fx[1]["text_embeds"]) < 0.03
+        emb, pl = O.sdxl_encode_prompt(cfg, w["text"], w["text2"], fx[0]["input_ids"], fx[1]["input_ids"])
+        assert rel(torch.cat([h1, h2], -1), emb) < 0.03 and rel(pooled, pl) < 0.03
+        # rows are independent; the single-tower entry point refuses a two-tower model
+        assert torch.equal(eng.text_encode_tower(1, fx[1]["input_ids"][:1], pooled=True)[1], pooled[:1])
+        with pytest.raises(RuntimeError):
+            eng.text_encode(fx[0]["input_ids"])
+        # the product path of the stage: preprocess.encode_token_ids_sdxl = cat of the towers + pooled
+        from distdiff_amd.preprocess import encode_token_ids_sdxl
+        e2, p2 = encode_token_ids_sdxl(eng, fx[0]["input_ids"], fx[1]["input_ids"])
+        assert torch.equal(e2, torch.cat([h1, h2], -1).cpu()) and torch.equal(p2, pooled.cpu())
+    finally:
+        eng.close()
+
+
 def test_vae_encoder_vs_oracle_tiny(hip_lib):
     from distdiff_amd.config import tiny_config
     from distdiff_amd.weights import synthetic_weights
@@ -122,5 +155,39 @@ def test_sd15_shape_encoders_vs_oracle(hip_lib):
         assert rel(mom, mom_ref) < 0.03
         assert rel(lat, lat_ref) < 0.03
         assert rel(emb, emb_ref) < 0.03
+    finally:
+        eng.close()
+
+
+def test_sdxl_base_text_towers_full_size(hip_lib):
+    """The two text towers of the SDXL-base repo at their published sizes -- text_encoder/ = CLIP ViT-L/14 text (768 wide, 12 layers, 12
+    heads, quick_gelu), text_encoder_2/ = OpenCLIP ViT-bigG/14 text (1280 wide, 32 layers, 20 heads, gelu, text_projection 1280) -- 77
+    tokens, seeded synthetic weights, against the fp32 oracle (pinned to transformers by clip_fixture_sdxl.pt at test size).  The UNet
+    behind them is the test-size SDXL structure with cross_attention_dim 2048 = 768 + 1280.  bf16 storage through 31 residual layers:
+    hidden_states[-2] <= 2 % (measured 0.9 % / 1.25 %), pooled text_embeds <= 2 % (measured 1.3 %)."""
+    from distdiff_amd.config import TextConfig, sdxl_config, tiny_sdxl_config
+    from distdiff_amd.weights import synthetic_weights
+    from oracle import sd_oracle as O
+    cfg = tiny_sdxl_config(max_batch=2)
+    full = sdxl_config()
+    cfg.text, cfg.text2, cfg.text_len = TextConfig(), full.text2, 77
+    cfg.unet.cross_attention_dim, cfg.unet.add_text_dim = 2048, 1280
+    w = synthetic_weights(cfg, seed=0, num_classes=5, encoders=True)
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(1000, 40000, (4, 77), generator=g).int()
+    ids[:, 0] = 49406
+    ids2 = ids.clone()
+    for r, n in enumerate((6, 20, 76, 11)):
+        ids[r, n:] = 49407                      # tokenizer: eos, then eos as padding
+        ids2[r, n] = 49407
+        ids2[r, n + 1:] = 0                     # tokenizer_2: eos, then "!" (id 0) as padding
+    eng = _engine(cfg, w)
+    try:
+        h1 = eng.text_encode_tower(0, ids)
+        h2, pooled = eng.text_encode_tower(1, ids2, pooled=True)
+        emb, pl = O.sdxl_encode_prompt(cfg, w["text"], w["text2"], ids, ids2)
+        e = (rel(h1, emb[..., :768]), rel(h2, emb[..., 768:]), rel(pooled, pl))
+        print("SDXL-base text towers: ViT-L hidden[-2] %.4f  bigG hidden[-2] %.4f  pooled %.4f" % e)
+        assert e[0] < 0.02 and e[1] < 0.02 and e[2] < 0.02, e
     finally:
         eng.close()

@@ -174,6 +174,40 @@ def test_clip_text_oracle_matches_transformers_fixture():
         assert torch.equal(out2[:, :7], out[:, :7]) and not torch.equal(out2[:, 7:], out[:, 7:])
 
 
+def test_clip_text_oracle_sdxl_towers_match_transformers_fixture():
+    """SDXL's text side (StableDiffusionXLPipeline.encode_prompt): oracle hidden_states[-2] of both towers and text_embeds of the second
+    vs the vectors recorded from transformers' CLIPTextModel / CLIPTextModelWithProjection (tests/golden/make_clip_fixture.py)."""
+    import os
+    from distdiff_amd.config import tiny_sdxl_config
+    from distdiff_amd.weights import synthetic_text_encoder
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "clip_fixture_sdxl.pt"), weights_only=False)
+    cfg = tiny_sdxl_config()
+    assert [t["which"] for t in fx["towers"]] == [0, 1]
+    hid = []
+    for t in fx["towers"]:
+        sd = synthetic_text_encoder(cfg, 0, which=t["which"])
+        tc = cfg.text2 if t["which"] else cfg.text
+        assert t["n_hidden_states"] == tc.num_hidden_layers + 1
+        if t["which"]:
+            h, pooled = O.clip_text_encode(cfg, sd, t["input_ids"], which=1, hidden_layer=-2, pooled=True)
+            assert pooled.shape == (4, tc.projection_dim)
+            assert (pooled - t["text_embeds"]).abs().max().item() < 1e-4
+            # the pooled token is the FIRST position of the largest id: padding behind it (id 0 here) must not matter
+            ids2 = t["input_ids"].clone()
+            ids2[0, 7:] = 5
+            assert torch.allclose(O.clip_text_encode(cfg, sd, ids2, which=1, hidden_layer=-2, pooled=True)[1][0], pooled[0], atol=1e-6)
+        else:
+            h = O.clip_text_encode(cfg, sd, t["input_ids"], which=0, hidden_layer=-2)
+        assert (h - t["hidden_m2"]).abs().max().item() < 1e-4
+        # hidden_states[-2] is not the final output
+        assert not torch.allclose(h, O.clip_text_encode(cfg, sd, t["input_ids"], which=t["which"]), atol=1e-3)
+        hid.append(h)
+    emb, pooled = O.sdxl_encode_prompt(cfg, synthetic_text_encoder(cfg, 0, 0), synthetic_text_encoder(cfg, 0, 1),
+                                       fx["towers"][0]["input_ids"], fx["towers"][1]["input_ids"])
+    assert emb.shape[-1] == cfg.unet.cross_attention_dim and torch.equal(emb, torch.cat(hid, -1))
+    assert pooled.shape[-1] == cfg.unet.add_text_dim
+
+
 def test_vae_encode_oracle_primitives():
     """the encoder downsample is F.pad(0,1,0,1) + stride-2 conv; the sample is mean + exp(logvar/2) * noise, times scaling_factor."""
     from distdiff_amd.config import tiny_config
