@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   const int Wd = 1 << lw, W2 = Wd + 2;
 
   // ---- tile of this workgroup (n-tiles fastest; blocks b, b + 8, ... share an XCD)
-  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn;
+  const int ntn = (p.N + BN - 1) / BN, tiles = (p.M / BM) * ntn;      // (N < BN: the narrow form TN = 1, one n-tile)
   int tile;
   {
     const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 
   // ---- per-tap offsets: lane t holds tap t ((dy + 32) << 6 | (dx + 32)); read with readlane where needed
   const int v_taps = lane < 9 ? p.taptab[lane] : 0;
-  if (tid < BN) bias_s[tid] = (p.flags & CF_BIAS) ? p.bias[n0 + tid] : 0.f;
+  if (tid < BN) bias_s[tid] = ((p.flags & CF_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
 
   // ---- weight staging: wave w moves pieces w, w + 8, ... (8 rows x 128 B) of the BN weight rows of a K-step.  LDS row R of a wave's
   // TN * 16 span holds output channel chan_of_row(R): tiles are paired so that a lane's 4 + 4 accumulator rows of a pair are 8
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     const int R = (wave + 8 * i) * 8 + prow;
     const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
     const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
-    woff[i] = ((NPC & 7) == 0 || R < BN) ? ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u : OOB;
+    // (rows behind the last output channel -- the narrow form pads N = 3 / 4 to a 32-row stage -- read as zeros: out of range)
+    woff[i] = (((NPC & 7) == 0 || R < BN) && n0 + ch < p.N) ? ((unsigned)(n0 + ch) * (unsigned)p.K + (unsigned)(jw * 8)) * 2u : OOB;
   }
   auto issue_w = [&](int kt, int i) {
     if ((NPC & 7) == 0 || wave + 8 * i < NPC) hdma16(p.w, smem + (kt & 1) * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)(c_begin * 9 + kt) * 128u);
@@ -293,6 +294,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   // not hidden by anything: tools/micro/pingpong_gemm.hip, four 32-row strips per K-step cost 0.5 us of barrier skeleton per K-step,
   // two K halves 0.35), TN + 8 fragments live instead of 2 TN + 4.
   bf16x8 wf[TN], xf[8];
+  // (narrow form, TN = 1: the second column wave of a row group only multiplies zero padding, columns 16 .. 31.  Letting it skip its
+  // fragment reads and MFMAs measured SLOWER -- 1206 -> 1504 us on the decoder's conv_out: the form is bound by the exposed halo refill
+  // of its two short chunks, not by LDS reads, and the branch cost the schedule.)
   int kt = 0;
   for (int c = c_begin; c < c_end; ++c) {
     if (c > c_begin) {
@@ -374,7 +378,31 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
     }
     return;
   }
-  pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s, 0, fr, fq);
+  if constexpr (TN == 1) {
+    // narrow form (conv_out: N <= 4): channels 0 .. 3 of a pixel are the four accumulator rows of lane group 0 of the first column wave;
+    // bias only; fp32 (CF_OUT_F32: the image / eps rows are 8 floats wide and only the N valid ones may be written) or bf16 output
+    if (wc == 0 && fq == 0) {
+      const float4 b4 = *(const float4*)bias_s;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int m = m_of(wr * 128 + a * 16 + fr);
+        const float v[4] = {acc[a][0][0] + b4.x, acc[a][0][1] + b4.y, acc[a][0][2] + b4.z, acc[a][0][3] + b4.w};
+        if (p.flags & CF_OUT_F32) {
+          float* yp = (float*)p.y + (size_t)m * p.y_ld;
+          if (p.N == 4) *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < p.N) yp[r] = v[r];
+        } else {
+          bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < p.N) yp[r] = f2bf(v[r]);
+        }
+      }
+    }
+  } else {
+    pp_epilogue<TN>(p, acc, m_of, wr, wc, n0, bias_s, bias_s, 0, fr, fq);
+  }
 }
 
 #ifdef DD_TRACE
@@ -607,7 +635,7 @@ hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t strea
   const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
-  const int tiles = (p.M / BM) * (p.N / BN);
+  const int tiles = (p.M / BM) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL((conv_halo_kernel<TN, WN, MI>), dim3(tiles, MI ? p.ksplit : 1), dim3(512), lds, stream, p, g);
   return hipGetLastError();
 }
@@ -627,21 +655,32 @@ int conv_halo_split(const ConvGemmParams& p) {
   return s;
 }
 
-// 0 = not eligible, else the tile form: 5 = 256 x 320, 4 = 256 x 256, 2 = 512 x 128 (N = 128).  The host reads the tap table once per weight tensor elsewhere: here the
+// 0 = not eligible, else the tile form: 5 = 256 x 320, 4 = 256 x 256, 6 = 512 x 160, 2 = 512 x 128 (N = 128), 1 = 512 x 32 (narrow: N <= 4).  The host reads the tap table once per weight tensor elsewhere: here the
 // caller guarantees a 3x3 / pad 1 table (ntaps == 9 with offsets in {-1, 0, 1}^2), which every packer emits for KH = KW = 3, pad = 1.
 int conv_halo_config(const ConvGemmParams& p) {
   static const int on = getenv("DD_CONV_HALO") ? atoi(getenv("DD_CONV_HALO")) : 1;
   if (!on || p.force_small) return 0;
   if (p.ntaps != 9 || p.stride != 1 || p.shift > 1 || p.parity || (p.H << p.shift) != p.Ho || (p.W << p.shift) != p.Wo || (p.cin & 63) ||
       p.K != 9 * p.cin) return 0;
-  if ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_GNFOLD)) || p.bias_sel) return 0;
+  // narrow outputs (conv_out of the decoder / the UNet, N <= 4): a 512 x 32 form whose weight stage is 4 KB -- the input tile is read once
+  // from HBM (halo) instead of being gathered tap by tap through the 128-wide tiles of the general kernels (60 of 64 columns wasted)
+  static const int narrow_on = getenv("DD_HALO_NARROW") ? atoi(getenv("DD_HALO_NARROW")) : 1;
+  const bool narrow = narrow_on && p.N <= 4 && !(p.flags & ~(CF_BIAS | CF_OUT_F32 | CF_GNFOLD)) && !p.bias_sel && !p.shift && p.ksplit <= 1;
+  if (!narrow && ((p.flags & ~(CF_BIAS | CF_RES | CF_RELU | CF_STATS | CF_GNFOLD)) || p.bias_sel)) return 0;
   if ((p.flags & CF_GNFOLD) && (!p.gn_coef || p.shift)) return 0;
   // tile forms by preference: 512 x 160 / 512 x 128 (the halo-resident input is cheap, the streamed weights are not: 20 / 16 KB of
   // weights + ~10 KB of halo per K-step instead of 40 / 32 + 5.6) where the image geometry allows 512-pixel tiles, else 256 x 320 / 256 x 256
   static const int tall = getenv("DD_HALO_TALL") ? atoi(getenv("DD_HALO_TALL")) : 1;
-  if ((p.y_ld & 7) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
+  if ((!narrow && (p.y_ld & 7)) || ((p.flags & CF_RES) && (p.res_ld & 7)) || (p.x_ld & 7) || p.alpha != 1.f) return 0;
   if ((size_t)p.H * p.W * (size_t)p.x_ld * 2 >= 0xF0000000ull) return 0;         // byte offsets are per image
   if (p.M != p.B * p.Ho * p.Wo) return 0;
+  if (narrow) {
+    HaloGeo g;
+    if (p.N == 4 && (p.flags & CF_OUT_F32) && (p.y_ld & 3)) return 0;             // float4 stores
+    if (!halo_geometry(p, 512, &g) || p.M / 512 < 192) return 0;
+    if (2 * 32 * 128 + ((g.halo_px + 7) & ~7) * 128 + 32 * 4 + 512 + 64 > 163840) return 0;
+    return 1;
+  }
   if (conv_halo_split(p) > 1) return 5;                  // 8 x 8 level: 256 x 320 multi-image tiles + chunk split (fp32 partials)
   if (p.ksplit > 1) return 0;
   const int forms[4][3] = {{6, 512, 160}, {2, 512, 128}, {5, 256, 320}, {4, 256, 256}};
@@ -705,7 +744,8 @@ extern "C" int dd_debug_read_pp_trace(unsigned long long* host, int n) {
 
 hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream) {
   HaloGeo g;
-  if (!halo_geometry(p, tn == 2 || tn == 6 ? 512 : 256, &g)) return hipErrorInvalidValue;
+  if (!halo_geometry(p, tn == 2 || tn == 6 || tn == 1 ? 512 : 256, &g)) return hipErrorInvalidValue;
+  if (tn == 1) return run_halo<1, 2>(p, g, stream);
   if (g.ipt > 1) return (tn == 5 && p.ksplit > 1) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
   return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

@@ -369,11 +369,17 @@ void plan_gn_stats(Program& P) {
   // Built, bit-identical to the separate kernels (tests/test_kernels_gpu.py::test_groupnorm_applied_by_the_halo_convolution) and
   // OFF by default: the apply runs once per tile, 64-channel chunk and n-tile while the matrix pipe waits (norm family 206 -> 155 ms,
   // conv family 1615 -> 1673 ms per 32-image step, same device, tools/ab_gn.sh): DD_GN_APPLY_FUSION=1 switches it on.
-  if (!P.f32 && getenv("DD_GN_APPLY_FUSION") && atoi(getenv("DD_GN_APPLY_FUSION")))
+  // DD_GN_NARROW_FUSION=1: only conv_norm_out -> conv_out (N <= 4, conv_halo_kernel<1, 2>).  Measured on the bench step, same box:
+  // conv_out on the narrow halo form 2098 -> 2089 ms per step; with its GroupNorm folded in as well 2095 ms (norm -3.5 ms, conv +8 ms:
+  // that form is bound by its exposed halo refill and the apply in LDS lengthens exactly that) -- off as well.
+  const bool fold_all = getenv("DD_GN_APPLY_FUSION") && atoi(getenv("DD_GN_APPLY_FUSION"));
+  const bool fold_narrow = getenv("DD_GN_NARROW_FUSION") && atoi(getenv("DD_GN_NARROW_FUSION"));
+  if (!P.f32 && (fold_all || fold_narrow))
     for (size_t gi = 0; gi + 1 < P.ops.size(); ++gi) {
       Op& g = P.ops[gi]; Op& cv = P.ops[gi + 1];
       if (g.kind != OP_GN || cv.kind != OP_CONV || cv.x != g.y || cv.x_fwd >= 0 || !P.t[g.y].transient) continue;
       if (cv.cw->KH != 3 || cv.cw->KW != 3 || cv.stride != 1 || cv.up || cv.cw->f32 || cv.cw->geglu) continue;
+      if (!fold_all && cv.cw->Cout > 4) continue;
       g.gn_into = (int)gi + 1; cv.gn_from = (int)gi;
     }
   if (P.f32 || getenv("DD_NO_GN_FUSION")) return;

@@ -145,6 +145,30 @@ def test_narrow_conv_fp32_output_in_padded_rows(ops):
     assert float((y[:, Cout:] - 7.0).abs().max()) == 0.0, "wrote outside the N valid channels"
 
 
+@pytest.mark.parametrize("case", [("decoder_conv_out_128to3_512px", 1, 128, 3, 512, 512, True), ("unet_conv_out_320to4_64px", 32, 320, 4, 64, 64, True),
+                                  ("narrow_bf16_out_64to2_128px", 8, 64, 2, 128, 128, False)], ids=lambda c: c[0])
+def test_narrow_conv_on_the_halo_form(ops, case):
+    """conv_out (N <= 4) on the 512 x 32 form of the halo kernel (conv_halo_kernel<1, 2>): the input tile is staged once per 64-channel
+    chunk, the weight stage is padded with out-of-range (zero) rows; fp32 output into 8-wide rows touches only the N valid channels."""
+    name, B, Cin, Cout, H, W, f32 = case
+    g = torch.Generator().manual_seed(33)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    xs = ops.to_nhwc_bf16(x, Cin).cuda()
+    pk = ops.PackedConv(w, 1, mode=0, bias=bias)
+    if f32:
+        y = torch.full((B * H * W, 8), 7.0, dtype=torch.float32, device="cuda")
+        ops.conv_gemm(xs, pk, B, H, W, H, W, y=y[:, :Cout], out_f32=True, ksplit=1)
+    else:
+        y = torch.full((B * H * W, 8), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.conv_gemm(xs, pk, B, H, W, H, W, y=y[:, :Cout], ksplit=1)
+    torch.cuda.synchronize()
+    assert_close(ops.from_nhwc(y[:, :Cout].float(), B, H, W), ref, rtol=5e-3 if f32 else 2e-2, atol=1e-3 if f32 else 2e-2, what=name)
+    assert float((y[:, Cout:].float() - 7.0).abs().max()) == 0.0, "wrote outside the N valid channels"
+
+
 def test_conv_general_staging_path_beyond_4gb(ops):
     """The decoder's 256-channel 512x512 level at the benchmarked batch: 34 x 512 x 512 x 256 bf16 = 4.56 GB of input.  The fast staging
     path of conv_gemm2.hip addresses the input through 32-bit BYTE offsets of a buffer resource, so inputs of 3.75 GB and more take the
@@ -175,7 +199,9 @@ def test_conv_general_staging_path_beyond_4gb(ops):
 
 
 @pytest.mark.parametrize("case", [("gnfold_320_32x32", 48, 320, 320, 32, 32, 32, True), ("gnfold_256_64x64_res", 12, 128, 256, 64, 64, 32, True),
-                                  ("gnfold_n128_nosilu", 1, 64, 128, 256, 512, 32, False)], ids=lambda c: c[0])
+                                  ("gnfold_n128_nosilu", 1, 64, 128, 256, 512, 32, False),
+                                  ("gnfold_conv_out_128to3_512px", 1, 128, 3, 512, 512, 32, True), ("gnfold_conv_out_320to4_64px", 32, 320, 4, 64, 64, 32, True)],
+                         ids=lambda c: c[0])
 def test_groupnorm_applied_by_the_halo_convolution(ops, case):
     """CF_GNFOLD: GroupNorm(+SiLU) -> 3x3 convolution (ResnetBlock2D norm1 -> conv1, norm2 -> conv2) with the normalisation applied to
     the convolution's staged input tile instead of a pass over the tensor: same result as GroupNorm -> conv through the separate
@@ -191,10 +217,19 @@ def test_groupnorm_applied_by_the_halo_convolution(ops, case):
     xd = ops.to_nhwc_bf16(x, Cin).cuda()
     pk = ops.PackedConv(w, 1, mode=0, bias=bias)
     coef, stats = ops.groupnorm_coef(xd, gamma.cuda(), beta.cuda(), B, H * W, G, 1e-5)
+    yn, _ = ops.groupnorm(xd, gamma.cuda(), beta.cuda(), B, H * W, G, 1e-5, silu)
+    if Cout <= 4:      # conv_norm_out -> conv_out as the engine runs it: fp32 output into 8-wide rows, the narrow form of the halo kernel
+        y = torch.zeros((B * H * W, 8), dtype=torch.float32, device="cuda")
+        ops.conv_gemm(xd, pk, B, H, W, H, W, y=y[:, :Cout], out_f32=True, gn_coef=coef, gn_silu=silu, ksplit=1)
+        y2 = torch.zeros((B * H * W, 8), dtype=torch.float32, device="cuda")
+        ops.conv_gemm(yn, pk, B, H, W, H, W, y=y2[:, :Cout], out_f32=True, ksplit=1)
+        torch.cuda.synchronize()
+        assert_close(ops.from_nhwc(y[:, :Cout], B, H, W), ref, rtol=5e-3, atol=2e-3, what=name + " vs torch")
+        assert torch.equal(y.cpu(), y2.cpu()), "folded and separate GroupNorm -> conv differ bitwise"
+        return
     y = ops.conv_gemm(xd, pk, B, H, W, H, W, gn_coef=coef, gn_silu=silu)
     torch.cuda.synchronize()
     assert_close(ops.from_nhwc(y, B, H, W), ref, what=name + " vs torch")
-    yn, _ = ops.groupnorm(xd, gamma.cuda(), beta.cuda(), B, H * W, G, 1e-5, silu)
     y2 = ops.conv_gemm(yn, pk, B, H, W, H, W)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), y2.cpu()), "folded and separate GroupNorm -> conv differ bitwise"

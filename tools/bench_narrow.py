@@ -1,4 +1,4 @@
-"""conv_out shapes (3x3, N = 3 / 4) through the op-level ABI: conv_narrow.hip against the tiled kernels (DD_CONV_NARROW=0)."""
+"""conv_out shapes (3x3, N = 3 / 4) through the op-level ABI: the 512 x 32 form of the halo kernel against the tiled kernels (DD_HALO_NARROW=0)."""
 import math, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
@@ -26,6 +26,6 @@ def run(B, Cin, Cout, H, W, iters=10):
     print("B %3d Cin %4d N %d %4dx%-4d: %8.1f us  %5.2f TB/s of input" % (B, Cin, Cout, H, W, us, M * Cin * 2 / us / 1e6), flush=True)
 
 
-print("narrow=" + os.environ.get("DD_CONV_NARROW", "1"))
+print("DD_HALO_NARROW=" + os.environ.get("DD_HALO_NARROW", "1"))
 run(32, 128, 3, 512, 512)
 run(64, 320, 4, 64, 64)
