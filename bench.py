@@ -222,7 +222,7 @@ def recorded_traffic(B, config):
     with open(path) as f:
         t = json.load(f)
     byts = launches = 0.0
-    for fam in ("conv_gemm_big_kernel", "conv_halo_kernel", "gemm_pp_kernel", "conv_gemm_kernel", "splitk"):
+    for fam in ("conv_gemm_big_kernel", "conv_halo_kernel", "gemm_pp_kernel", "gemm_ws_kernel", "conv_gemm_kernel", "splitk"):
         if fam in t:
             byts += t[fam]["hbm_fetch_bytes_corrected"] + t[fam]["hbm_write_bytes"]
             if fam != "splitk":

@@ -84,7 +84,7 @@ CF_LNFOLD, CF_ROWSTATS, CF_GNFOLD = 1024, 2048, 4096
 
 # every symbol declared in include/distdiff_hip_ops.h and include/distdiff_hip.h (checked by tests/test_abi.py)
 OPS_SYMBOLS = [
-    "dd_op_conv_gemm", "dd_op_groupnorm_fwd", "dd_op_groupnorm_bwd", "dd_op_groupnorm_scratch_bytes",
+    "dd_op_conv_gemm", "dd_op_conv_gemm_check", "dd_op_groupnorm_fwd", "dd_op_groupnorm_bwd", "dd_op_groupnorm_scratch_bytes",
     "dd_op_layernorm_fwd", "dd_op_layernorm_bwd", "dd_op_attention_fwd", "dd_op_attention_bwd",
     "dd_op_attention_gemm_workspace", "dd_op_attention_gemm_fwd", "dd_op_attention_gemm_bwd",
     "dd_pack_conv_weight", "dd_op_conv_f32", "dd_pack_conv_weight_f32", "dd_op_nchw_f32_to_nhwc_bf16", "dd_op_nhwc_to_nchw_f32", "dd_op_cfg_ddim",
@@ -103,6 +103,7 @@ ENGINE_SYMBOLS = [
 def _declare(l):
     i, f, sz = C.c_int, C.c_float, C.c_size_t
     l.dd_op_conv_gemm.argtypes = [C.POINTER(ConvGemmParams), sz, vp]
+    l.dd_op_conv_gemm_check.argtypes = [C.POINTER(ConvGemmParams), vp]
     l.dd_op_groupnorm_fwd.argtypes = [C.POINTER(GroupNormParams), vp]
     l.dd_op_groupnorm_bwd.argtypes = [C.POINTER(GroupNormParams), vp]
     l.dd_op_groupnorm_scratch_bytes.argtypes = [i, i]

@@ -11,6 +11,21 @@ int dd_op_conv_gemm(const ConvGemmParams* p, size_t cap, void* st) {
   // validates it when the weights are packed (distdiff_amd/ops.py: PackedConv.taptab_host), not here per launch.
   return (int)launch_conv_gemm(*p, cap, S(st));
 }
+int dd_op_conv_gemm_check(const ConvGemmParams* p, void* st) {
+  // The synchronous companion for ABI users who want the contract checked against the DEVICE table: waits for the stream, reads the
+  // tap table back and validates it (entries in range; a one-tap stride-1 same-size launch carries the centre tap).  0 = fine.
+  if (!p || !p->taptab || p->ntaps < 1 || p->ntaps > 64) return (int)hipErrorInvalidValue;
+  int taps[64];
+  hipError_t e = hipStreamSynchronize(S(st));
+  if (e == hipSuccess) e = hipMemcpy(taps, p->taptab, sizeof(int) * p->ntaps, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  for (int t = 0; t < p->ntaps; ++t) {
+    const int dy = ((taps[t] >> 6) & 63) - 32, dx = (taps[t] & 63) - 32;
+    if ((taps[t] >> 12) != 0 || dy < -31 || dy > 31 || dx < -31 || dx > 31) return (int)hipErrorInvalidValue;
+  }
+  if (p->ntaps == 1 && p->stride == 1 && !p->shift && p->H == p->Ho && p->W == p->Wo && taps[0] != ((32 << 6) | 32)) return (int)hipErrorInvalidValue;
+  return 0;
+}
 int dd_op_groupnorm_fwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_fwd(*p, S(st)); }
 int dd_op_groupnorm_bwd(const GroupNormParams* p, void* st) { return (int)launch_groupnorm_bwd(*p, S(st)); }
 size_t dd_op_groupnorm_scratch_bytes(int B, int G) { return groupnorm_scratch_bytes(B, G); }

@@ -39,7 +39,8 @@ class PackedConv:
                               wp.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), out4)
         self.w = torch.from_numpy(wp.view(np.int16)).to(device).view(torch.bfloat16)
         self.taptab = torch.from_numpy(tt).to(device)
-        self.taptab_host = tt                     # host copy: contract checks without a device round trip (conv_gemm)
+        self.taptab_host = tt.copy()              # host copy: contract checks without a device round trip (conv_gemm); read-only
+        self.taptab_host.setflags(write=False)
         self.geglu = bool(geglu) and mode == 0   # in dgrad form the permutation applies to K only
         self.bias = None
         if bias is not None:
@@ -103,7 +104,7 @@ def conv_f32(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask
 
 def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mask=None, relu=False, out_f32=False,
               ksplit=0, alpha=1.0, raw=None, y=None, x_ld=None, partial=None, force_small=False, stats=None, ln_stats=None, ln_c1=None,
-              rowpart=None, gn_coef=None, gn_silu=True):
+              rowpart=None, gn_coef=None, gn_silu=True, check_device_taps=False):
     """x: bf16 [B*H*W, x_ld]; returns y [B*Ho*Wo, N(or N/2 for GEGLU)].  stats: fp32 [M/64, C, 2] buffer (or a column view of one) to
     receive the per-(64-row block, channel) partial (mean, M2) of the stored values (CF_STATS; the launch fails if the kernel the
     launcher picks for this shape cannot emit them)."""
@@ -162,6 +163,8 @@ def conv_gemm(x, pk, B, H, W, Ho, Wo, stride=1, shift=0, parity=0, res=None, mas
         p.rowpart, p.rowpart_ld = _ptr(rowpart), rowpart.stride(0) // 2
     p.ksplit, p.flags, p.alpha = ksplit, flags, alpha
     p.force_small = int(force_small)
+    if check_device_taps:      # synchronous: the tap contract against the DEVICE table (dd_op_conv_gemm_check)
+        check(_lib.lib().dd_op_conv_gemm_check(C.byref(p), _stream()), "conv_gemm tap table check")
     check(_lib.lib().dd_op_conv_gemm(C.byref(p), cap, _stream()), "conv_gemm")
     return y
 

@@ -38,6 +38,9 @@ struct ConvF32Params;
  * entry point is stream-asynchronous and does not read device memory: the owner of the table checks it on the host when the weights
  * are packed (distdiff_amd/ops.py raises on any other single tap). */
 int dd_op_conv_gemm(const struct ConvGemmParams* p, size_t partial_cap_bytes, void* stream);
+/* Synchronous check of that contract against the DEVICE table (waits for the stream, copies the table back): 0 when every entry is in
+ * range and a pointwise launch carries the centre tap.  For ABI users without a host copy of their tables; never called by the engine. */
+int dd_op_conv_gemm_check(const struct ConvGemmParams* p, void* stream);
 int dd_op_groupnorm_fwd(const struct GroupNormParams* p, void* stream);
 int dd_op_groupnorm_bwd(const struct GroupNormParams* p, void* stream);
 size_t dd_op_groupnorm_scratch_bytes(int B, int G);

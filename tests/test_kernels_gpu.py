@@ -265,18 +265,32 @@ def test_linear_epilogues(ops):
 
 def test_pointwise_launch_requires_the_centre_tap(ops):
     """dd_op_conv_gemm: a one-tap, stride-1, same-size launch is a 1x1 / linear layer; the persistent kernel does not read its tap
-    table, so the host side rejects a table that holds anything but the centre tap instead of silently computing the centre tap --
-    on the host copy kept at pack time (the launch entry point never synchronises)."""
-    from distdiff_amd import _lib
+    table.  The asynchronous entry point never reads device memory: ops.conv_gemm checks the READ-ONLY host copy kept at pack time, and
+    dd_op_conv_gemm_check is the synchronous companion that validates the DEVICE table (a table that diverged from the host copy)."""
     g = torch.Generator().manual_seed(12)
     M, K, N = 2048, 256, 256
     x = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
     pk = ops.PackedConv(bf(torch.randn(N, K, generator=g) / 16), 0)
     assert int(pk.taptab[0]) == (32 << 6) | 32 == int(pk.taptab_host[0])
-    ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
-    pk.taptab[0] = pk.taptab_host[0] = ((32 + 1) << 6) | 32          # dy = +1
+    ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1, check_device_taps=True)
+    with pytest.raises(ValueError):
+        pk.taptab_host[0] = 0                                          # the host copy cannot be edited
+    pk.taptab[0] = ((32 + 1) << 6) | 32                                # the device table diverges: dy = +1
+    ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)                      # the asynchronous launch cannot see it (documented contract) ...
     with pytest.raises(RuntimeError):
-        ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1)
+        ops.conv_gemm(x, pk, 1, M, 1, M, 1, ksplit=1, check_device_taps=True)     # ... the synchronous check does
+    # a host copy with a non-centre single tap is refused without touching the device
+    pk2 = ops.PackedConv(bf(torch.randn(N, K, generator=g) / 16), 0)
+    bad = pk2.taptab_host.copy()
+    bad[0] = ((32 + 1) << 6) | 32
+    bad.setflags(write=False)
+    pk2.taptab_host = bad
+    with pytest.raises(RuntimeError):
+        ops.conv_gemm(x, pk2, 1, M, 1, M, 1, ksplit=1)
+    # 3x3 tables pass the device check
+    pk3 = ops.PackedConv(bf(torch.randn(64, 64, 3, 3, generator=g) / 24), 1)
+    x3 = bf(torch.randn(1024, 64, generator=g)).to(torch.bfloat16).cuda()
+    ops.conv_gemm(x3, pk3, 1, 32, 32, 32, 32, check_device_taps=True)
 
 
 @pytest.mark.parametrize("M,K,Fd", [(200, 128, 256), (1500, 320, 1280), (12288, 320, 512), (16384, 640, 1280)])   # the last two: persistent ping-pong GEMM, 256 x 256 tiles
