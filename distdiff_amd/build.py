@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libdistdiff_hip.so")
-SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "conv_halo.hip", "gemm_ws.hip", "norm.hip", "attention.hip", "attention_gemm.hip", "elementwise.hip", "guide_f32.hip", "weights.cpp", "ops_abi.cpp",
+SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "conv_halo.hip", "gemm_ws.hip", "norm.hip", "attention.hip", "attention_shortk.hip", "attention_gemm.hip", "elementwise.hip", "guide_f32.hip", "weights.cpp", "ops_abi.cpp",
            "engine_weights.cpp", "engine_graph.cpp", "engine_exec.cpp", "engine.cpp"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs. With the default heuristic the attention kernels put them in AccVGPRs
 # and paid 144 v_accvgpr_read/write per KV tile to run the softmax on them (found in the ISA; attention family 475 -> see DESIGN.md)

@@ -1035,6 +1035,7 @@ static bool attn_short(const AttnParams& p) {
 
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t s) {
   if (!attn_check(p)) return hipErrorInvalidValue;
+  if (attention_shortk_supported(p)) return launch_attention_fwd_shortk(p, s);     // <= 80 keys: K / V resident, per-wave query tiles
   switch (p.D) {
     case 32: return run_fwd<32, 2, 64, 1>(p, s);
 #ifndef DD_A40_QT

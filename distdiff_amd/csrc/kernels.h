@@ -147,6 +147,9 @@ struct AttnParams {
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);
+// short key sequences (<= 80 keys: the 77-token cross-attention), attention_shortk.hip; launch_attention_fwd takes it when it applies
+bool attention_shortk_supported(const AttnParams& p);
+hipError_t launch_attention_fwd_shortk(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_delta(const AttnParams& p, hipStream_t stream);   // delta[b,h,q] = sum_d dO*O (first stage of the backward)
 // Wide heads (d >= 256: the AutoencoderKL mid-block attention) through the GEMM kernel with a materialised N x N score matrix per image
 // (attention_gemm.hip).  workspace: at least attention_gemm_workspace() bytes (one image); with more, single-head layers run up to 8

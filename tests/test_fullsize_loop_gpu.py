@@ -35,17 +35,20 @@ LOOSE = os.environ.get("DD_LOOP_MEASURE") == "1"      # print the measurements w
 # bounds = 1.25 x the worst row measured on MI355X with the round-5 binary (PSNR: 1.25 x the rms error = -1.94 dB); measured values:
 #   c1  latents 0.0200, PSNR 43.29 dB, max abs 0.0656, u8 bytes differing 0.716 (by > 2 levels 0.1485), score 1.1e-4
 #   c3  latents 0.0136, PSNR 46.28 dB, max abs 0.0312, u8 0.642 (0.0557), score < 1e-5
-C1 = {"z_rel": 0.025, "psnr": 41.3, "img_max": 0.082, "u8_diff": 0.80, "u8_gt2": 0.186, "score_rel": 2.5e-4}
-C3 = {"z_rel": 0.017, "psnr": 44.3, "img_max": 0.039, "u8_diff": 0.75, "u8_gt2": 0.070, "score_rel": 5e-5}
+# (re-derived on the final round-5 binary -- the short-key cross-attention kernel rounds differently from the streaming one, equally
+#  accurate per op (tools/xattn_acc.py), and these whole-loop measures move with every such change: c1 2.00 -> 1.77 %, s1 1.71 -> 1.51 %,
+#  qk14 1.44 -> 1.76 %.  Measured: c1 0.0177 / 44.76 dB / 0.0380 / 0.683 (0.0982) / 6e-5; c3 0.0135 / 46.32 dB / 0.0296 / 0.643 (0.0540) / 0)
+C1 = {"z_rel": 0.0221, "psnr": 42.7, "img_max": 0.0475, "u8_diff": 0.76, "u8_gt2": 0.123, "score_rel": 1.5e-4}
+C3 = {"z_rel": 0.0169, "psnr": 44.3, "img_max": 0.037, "u8_diff": 0.72, "u8_gt2": 0.0675, "score_rel": 5e-5}
 # the other weight draws (tests/test_fullsize_loop_draws_gpu.py); measured:
-#   s1    latents 0.0171, PSNR 44.05 dB, max abs 0.0436, u8 0.680 (0.1207), score 4e-5
+#   s1    latents 0.0151, PSNR 45.25 dB, max abs 0.0361, u8 0.656 (0.0846), score 6e-5
 #   qk14  (scores x 2 in every block, well conditioned: oracle eps moves 0.0023 under one bf16 rounding of its input)
-#         latents 0.0144, PSNR 45.15 dB, max abs 0.0616, u8 0.658 (0.0838), score 9e-5; +0.001 per step like the flat draws
+#         latents 0.0176, PSNR 44.34 dB, max abs 0.0498, u8 0.683 (0.1120), score 1.3e-4; +0.001 per step like the flat draws
 #   qk2   (scores x 4 in every block, ILL-conditioned: the oracle's own fp16 / bf16 executions of the tiny loop are 21 % / 27 % from its
-#         fp32 run, tests/test_oracle.py) latents 0.193, PSNR 24.65 dB: error grows by a steady 0.8 % per step (1.1 % after the first step
+#         fp32 run, tests/test_oracle.py) latents 0.178, PSNR 25.28 dB: error grows by a steady 0.8 % per step (1.1 % after the first step
 #         against 0.73 % for ONE bf16 rounding of the oracle's input); bounded by that reduced-precision family, not a parity claim
-CW = {"s1": {"z_rel": 0.0214, "psnr": 42.1, "img_max": 0.0545, "u8_diff": 0.78, "u8_gt2": 0.151, "score_rel": 1e-4},
-      "qk14": {"z_rel": 0.018, "psnr": 43.2, "img_max": 0.077, "u8_diff": 0.75, "u8_gt2": 0.105, "score_rel": 2e-4},
+CW = {"s1": {"z_rel": 0.0189, "psnr": 43.2, "img_max": 0.0451, "u8_diff": 0.74, "u8_gt2": 0.106, "score_rel": 1.5e-4},
+      "qk14": {"z_rel": 0.022, "psnr": 42.3, "img_max": 0.0623, "u8_diff": 0.76, "u8_gt2": 0.14, "score_rel": 2.6e-4},
       "qk2": {"z_rel": 0.30, "psnr": 21.0, "img_max": 0.50, "u8_diff": 0.97, "u8_gt2": 0.92, "score_rel": 1.5e-3}}
 
 

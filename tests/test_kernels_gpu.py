@@ -537,6 +537,45 @@ def test_attention(ops, case):
         assert_close(dv.reshape(B, Nk, H, D), gv, rtol=3e-2, atol=3e-3, what=name + " dV")
 
 
+SHORTK_CASES = [("cross77_d40_4096q", 1, 8, 4096, 77, 40, False), ("cross77_d40_prescaled", 2, 8, 1024, 77, 40, True), ("cross77_d80", 2, 8, 1024, 77, 80, True),
+                ("cross77_d64_sdxl", 1, 10, 4096, 77, 64, True), ("cross80_d40_full_last_tile", 1, 4, 512, 80, 40, False),
+                ("cross1_d40_single_key", 1, 2, 64, 1, 40, False), ("cross65_d80", 1, 4, 96, 65, 80, False), ("cross16_d64_one_tile", 2, 2, 32, 16, 64, True),
+                ("cross77_d40_many_tiles_per_wave", 8, 8, 4096, 77, 40, True)]
+
+
+@pytest.mark.parametrize("case", SHORTK_CASES, ids=[c[0] for c in SHORTK_CASES])
+def test_attention_short_keys(ops, case):
+    """attention_shortk.hip: <= 80 keys (the 77-token cross-attention), K / V resident per workgroup, every wave walking its own 32-query
+    tiles with the next tile's Q rows requested by LDS-DMA behind hand-counted waits; exact one-pass softmax.  O, LSE and the dQ the
+    streaming backward derives from that LSE against torch; plain and prescaled queries; 1 .. 80 keys; one to eight tiles per wave; strided
+    (column-view) Q / O rows as the engine passes them."""
+    name, B, H, Nq, Nk, D, pre = case
+    g = torch.Generator().manual_seed(len(name))
+    scale = 1.0 / math.sqrt(D)
+    q = bf(torch.randn(B, Nq, H, D, generator=g) * 1.3)
+    k = bf(torch.randn(B, Nk, H, D, generator=g) * 1.3)
+    v = bf(torch.randn(B, Nk, H, D, generator=g))
+    if Nk > 2:
+        k[0, Nk // 2, 0] *= 5.0            # a spiked key
+        k = bf(k)
+    qs = bf(q * (scale * 1.4426950408889634)) if pre else q          # what the engine's to_q produces when the scale is folded in
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qs if pre else q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * (0.6931471805599453 if pre else scale)
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr)
+    d_o = bf(torch.randn(B, Nq, H, D, generator=g))
+    (gq,) = torch.autograd.grad(ref, (qr,), d_o)
+    # Q lives inside a wider row (fused projections are consumed through column views)
+    qw = torch.zeros((B * Nq, H * D + 64), dtype=torch.bfloat16, device="cuda")
+    qw[:, 64:] = (qs if pre else q).reshape(B * Nq, H * D).to(torch.bfloat16).cuda()
+    dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+    o, lse, dq, _, _ = ops.attention(qw[:, 64:], dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, 0.6931471805599453 if pre else scale,
+                                     d_o=dev(d_o, Nq), need_dkv=False, q_prescaled=pre)
+    torch.cuda.synchronize()
+    assert_close(o.reshape(B, Nq, H, D), ref.detach(), rtol=2e-2, atol=2e-3, what=name + " O")
+    assert_close(lse, torch.logsumexp(s.detach(), dim=-1), rtol=1e-3, atol=1e-3, what=name + " LSE")
+    assert_close(dq.reshape(B, Nq, H, D), gq, rtol=3e-2, atol=3e-3, what=name + " dQ")
+
+
 PRE_CASES = [("self_d40", 2, 8, 512, 512, 40, 1.0), ("self_d40_peaky", 1, 8, 1024, 2048, 40, 2.0), ("cross77_d40", 2, 8, 256, 77, 40, 1.0),
              ("self_d64", 1, 2, 200, 200, 64, 1.5), ("self_d80", 1, 4, 256, 320, 80, 1.5), ("self_d160", 1, 2, 64, 64, 160, 1.0),
              # fewer keys than one 64-key tile (the tiny config's 4x4 / 8x8 levels and its 13-token prompt): the first tile is also the ragged one
