@@ -8,6 +8,7 @@ scripts/exps/expand_diff.sh: strength 0.5 -> 25 executed steps, guidance_step 20
 ResNet-50 guide, bf16 MFMA with fp32 accumulation. Weights are seeded synthetic (no checkpoints offline).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 ...          # launches its own 8 ranks (distdiff_amd.launcher.spawn_ranks) BEFORE any GPU call
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Multi-GPU: one process per GPU, images sharded across ranks with the reference's partition function
@@ -23,17 +24,21 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s; AMD's 5 PFLOP/s headline includes 2:1 sparsity).
+# SURVEY.md section 8d prices the roofline against "the judge-supplied figure": DD_PEAK_BF16_TFLOPS overrides the guide's number.
+PEAK_BF16_TFLOPS = float(os.environ.get("DD_PEAK_BF16_TFLOPS", 2500.0))
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node to run on (default: WORLD_SIZE under torch.distributed.run, else 1).  Started plainly with "
+                         "N > 1 the script launches its own N ranks, one per GPU; under torch.distributed.run N must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0,
-                    help="images per step per GPU; 0 = the largest of 32 / 16 / 8 whose workspace (5.7 GB per image at 512x512: two activation "
-                         "stashes for the chained guided steps + the gradient slab) fits the free HBM of every rank")
+                    help="images per step per GPU; 0 = the largest of 32 / 16 / 8 whose workspace (distdiff_amd.engine.batch_for_free_hbm: two "
+                         "activation stashes for the chained guided steps + the gradient slab) fits the free HBM of every rank")
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny", "sdxl"],
                     help="sd15 = BASELINE configs[1] (the metric's workload); sdxl = the SDXL-base UNet at 1024x1024 (configs[4] structure, bf16)")
     ap.add_argument("--guidance", default="transform_guidance", choices=["transform_guidance", "direct_guidance", "none"])
@@ -44,8 +49,67 @@ def parse():
     ap.add_argument("--classes", type=int, default=100, help="classes of the prototype tables (100: Caltech-101-shaped configs[1]; 196: StanfordCars-shaped configs[3])")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
-    ap.add_argument("--no_cli", action="store_true", help="skip the output-stage extra (the CLI loop + PNG writer on 128 units, outside the timed region)")
-    return ap.parse_args()
+    ap.add_argument("--no_cli", action="store_true", help="skip the output-stage extra (the CLI loop + PNG writer, outside the timed region)")
+    ap.add_argument("--cli_units", type=int, default=0, help="units of the output-stage extra (0 = 12 engine batches)")
+    ap.add_argument("--no_strength1", action="store_true", help="skip the SURVEY 8(d) case (ii) extra (strength 1.0 = every schedule step executed; 2 timed steps)")
+    ap.add_argument("--harness_stub", action="store_true",
+                    help="TEST HOOK, not a measurement: gloo on the CPU and a sleeping stand-in for the engine, so that the launch / shard / "
+                         "timing / one-JSON-line logic of this entry point runs where there is no GPU (tests/test_bench_harness.py); the line "
+                         "says so in `metric`, `data` and `stub`")
+    return ap.parse_args(argv)
+
+
+def resolve_world(gpus, environ):
+    """(world, self_launch): what `--gpus` means next to the launcher's environment.
+      * RANK set (torch.distributed.run or our own spawn_ranks): world = WORLD_SIZE; a `--gpus` that disagrees is an error, never a
+        line with the wrong n_gpus
+      * RANK not set: `--gpus N > 1` -> this process only launches N ranks of itself; N in (None, 1) -> a single process, no process group"""
+    if "RANK" in environ:
+        world = int(environ.get("WORLD_SIZE", "1"))
+        if gpus is not None and gpus != world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+        return world, False
+    n = 1 if gpus is None else gpus
+    if n < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    return n, n > 1
+
+
+def self_launch(n, argv, stub):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    127.0.0.1 rendezvous, siblings of a failed rank stopped) and return the exit code.  The parent makes NO GPU call (GPUs are counted
+    from sysfs / the visibility variables); rank 0's child writes the one JSON line to the stdout it inherits."""
+    from distdiff_amd.launcher import spawn_ranks, visible_gpu_count
+    if not stub:
+        have = visible_gpu_count()
+        if have < n:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) are visible on this node" % (n, have))
+    return spawn_ranks(n, argv, script=os.path.abspath(__file__))
+
+
+class _StubEngine:
+    """--harness_stub only: stands where the engine stands so that main()'s control flow runs without a GPU.  Computes nothing."""
+    def __init__(self, B, L):
+        self.B, self.L, self.n = B, L, 0
+        self.shards = []
+
+    def set_schedule(self, *a, **k): pass
+    def set_prototypes(self, *a, **k): pass
+    def set_prompt(self, *a, **k): pass
+    def profile_enable(self, on): pass
+    def profile_read(self): return None
+    def workspace_bytes(self): return 0
+    def close(self): pass
+
+    def flops_last(self):
+        n, self.n = self.n, 0
+        return float(n)
+
+    def expand(self, lat, noise, e, b, tg, si, gt, gfirst, gcount, want_image=True):
+        assert lat.shape[0] == self.B, "ragged stub batch: %s" % (lat.shape,)
+        time.sleep(0.01)
+        self.n += self.B
+        return lat.clone(), torch.zeros(self.B, 3, 8, 8), torch.zeros(())
 
 
 def cpu_baseline(cfg, weights, n_exec, P, flops_per_image):
@@ -237,11 +301,15 @@ def recorded_traffic(B, config):
                                     "weight bytes and tile selection do not)" % (pb, float(B) / pb)}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse(argv)
+    world, launch = resolve_world(a.gpus, os.environ)
+    if launch:                                    # plain `python bench.py --gpus N`: become the launcher, touch no GPU
+        raise SystemExit(self_launch(world, argv, a.harness_stub))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = a.harness_stub
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # stdout carries exactly ONE JSON line: everything else that libraries print there (RCCL writes its NCCL_DEBUG=VERSION banner to
     # stdout when the first communicator is created) is sent to stderr by pointing fd 1 at fd 2 for the life of the process; the result
@@ -249,22 +317,33 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    distributed = "RANK" in os.environ            # launched by torch.distributed.run (also with --nproc-per-node 1)
-    if distributed:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    distributed = "RANK" in os.environ            # launched by torch.distributed.run or self_launch (also with one rank)
+    if stub:
+        dev = torch.device("cpu")
+        if distributed:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+        if local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d wants GPU %d but this process sees %d" % (rank, local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if distributed:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=dev)
 
     from distdiff_amd.config import sd15_config, sdxl_config, tiny_config
-    from distdiff_amd.engine import Engine
     from distdiff_amd.launcher import build_engine_distributed, shard_range
     from distdiff_amd.scheduler import DDIMSchedule
-    from distdiff_amd.weights import synthetic_weights
+    if not stub:
+        from distdiff_amd.engine import Engine
+        from distdiff_amd.weights import synthetic_weights
 
     B = a.batch
+    if B <= 0 and stub:
+        B = 4
     if B <= 0:
         if a.config == "sd15":
             from distdiff_amd.engine import batch_for_free_hbm
@@ -288,7 +367,9 @@ def main():
     def make_engine(c, w, layout):
         return Engine(c, w, enable_grad=guided, max_guidance_period=stash, device=str(dev), layout=layout)
 
-    if distributed and (world > 1 or os.environ.get("DD_FORCE_BROADCAST")):     # the env switch rehearses the RCCL start-up path on 1 GPU
+    if stub:
+        eng = _StubEngine(B, cfg.latent_size)
+    elif distributed and (world > 1 or os.environ.get("DD_FORCE_BROADCAST")):     # the env switch rehearses the RCCL start-up path on 1 GPU
         # rank 0 synthesises + packs the weights once; the PACKED device buffers reach the other ranks in one RCCL broadcast over xGMI
         def load():
             nonlocal weights
@@ -311,6 +392,10 @@ def main():
     # synthetic dataset shard: the global image list is split across ranks like generate_data.py:1003-1007
     n_total = B * world * (a.steps + a.warmup)
     mine = shard_range(n_total, world, rank)
+    shards = [(rank, mine[0], mine[-1] + 1)]
+    if distributed and world > 1:
+        shards = [None] * world
+        dist.all_gather_object(shards, (rank, mine[0], mine[-1] + 1))
     L = cfg.latent_size
     gd = torch.Generator().manual_seed(42 + rank)
     lat = (torch.randn(len(mine), 4, L, L, generator=gd) * 0.18215 * 5).to(dev)
@@ -330,16 +415,21 @@ def main():
     n_exec = len(ts) - si
     setup_s = time.time() - t_setup
 
-    def step(i):
+    def step(i, start=None):
         sl = slice(i * B, (i + 1) * B)
-        return eng.expand(lat[sl], noise[sl], e[sl], b[sl], targets[sl], si, gtype, gfirst, a.guidance_period, want_image=True)
+        return eng.expand(lat[sl], noise[sl], e[sl], b[sl], targets[sl], si if start is None else start, gtype, gfirst, a.guidance_period,
+                          want_image=True)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if distributed:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     prof = None
 
@@ -369,21 +459,24 @@ def main():
     dt, (z, img, score) = timed_steps(counted_step, a.steps, a.warmup, barrier, reduce_max, (prof_on, prof_off))
     flops = eng.flops_last()
     assert torch.isfinite(img).all() and torch.isfinite(z).all(), "non-finite output"
+    assert sum(hi - lo for _, lo, hi in shards) == n_total and len({r for r, _, _ in shards}) == world, shards
 
     images, rate = job_rate(a.steps, B, world, dt)
     flops_per_image = flops / (a.steps * B)
     if rank == 0:
         out = {
-            "metric": "512x512 images/sec/node, Caltech-101 5x expand, 50 DDIM steps + energy guidance",
+            "metric": ("HARNESS STUB (no GPU work, not a measurement): " if stub else "") +
+                      "512x512 images/sec/node, Caltech-101 5x expand, 50 DDIM steps + energy guidance",
             "value": rate, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "stub" if stub else "synthetic",
             "config": {"workload": ("BASELINE configs[4] structure: SDXL-base UNet shapes (bf16 attention), " if a.config == "sdxl" else
                                     ("BASELINE configs[3] (StanfordCars sizes): SD-1.5 shapes " if C_cls == 196 else "BASELINE configs[1]: SD-1.5 shapes ")) +
                                    "%dx%d, %d-step DDIM schedule, strength %.2f (%d executed steps), "
                                    "CFG 7.5, %s P=%d (class+group prototypes C=%d K=3 D=%d, ResNet-50 guide), final VAE decode"
                                    % (8 * L, 8 * L, len(ts), a.strength, n_exec, a.guidance, a.guidance_period, C_cls, D),
                        "images_per_step_per_gpu": B, "sharding": "image shards per rank (generate_data.py:1003-1007), no data-path collective",
+                       "shards": [[int(r), int(lo), int(hi)] for r, lo, hi in sorted(shards)],
                        "weights": "seeded synthetic, exact SD-1.x / AutoencoderKL / ResNet-50 shapes",
                        "algorithmic_tflop_per_image": flops_per_image / 1e12,
                        "flop_note": "FLOPs the engine executed (2 per MAC, dgrad-only VJP); the part of the UNet in front of the first "
@@ -393,6 +486,8 @@ def main():
             "e2e_tflops_per_gpu": flops / dt / 1e12,
             "e2e_frac_of_bf16_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
+        if stub:
+            out["stub"] = True
         if prof is not None:
             cv = prof["conv_gemm"]
             ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
@@ -405,12 +500,28 @@ def main():
         # the metric is on record before the extras run (they drive the PNG writer threads and a CPU oracle: a hang there must not lose it)
         sys.stderr.write("[bench] measured, extras pending: " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}) + "\n")
         sys.stderr.flush()
-        if world == 1 and not a.no_cli and a.config == "sd15":
+        if world == 1 and not stub and not a.no_strength1 and a.config == "sd15" and a.strength < 1.0:
+            # SURVEY.md section 8(d) case (ii): strength 1.0 = every step of the schedule executed (generate_data.py:1174 start index 0),
+            # the same guidance window; 1 untimed + 2 timed steps on the engine and inputs of the main measurement
             try:
-                out["output_stage"] = cli_rate(eng, cfg, sched, a, B)
+                nb = a.steps + a.warmup
+                step(0, 0)
+                sync()
+                t0 = time.time()
+                for i in range(2):
+                    step((1 + i) % nb, 0)
+                sync()
+                d1 = (time.time() - t0) / 2
+                out["strength1"] = {"value": B / d1, "unit": "images/s", "ms_per_step": 1000.0 * d1, "steps": 2, "executed_ddim_steps": len(ts),
+                                    "note": "strength 1.0 (all %d schedule steps executed), otherwise the main line's workload" % len(ts)}
+            except Exception as ex:
+                out["strength1"] = {"value": None, "note": "failed: %r" % (ex,)}
+        if world == 1 and not stub and not a.no_cli and a.config == "sd15":
+            try:
+                out["output_stage"] = cli_rate(eng, cfg, sched, a, B, a.cli_units or 12 * B)
             except Exception as ex:      # an extra, never the metric
                 out["output_stage"] = {"cli_images_per_s": None, "cli_note": "failed: %r" % (ex,)}
-        if world == 1 and not a.no_cpu_baseline and a.config == "sd15":
+        if world == 1 and not stub and not a.no_cpu_baseline and a.config == "sd15":
             try:
                 wcpu = weights
                 out["cpu_baseline"] = cpu_baseline(cfg, wcpu, n_exec, a.guidance_period, flops_per_image)

@@ -88,9 +88,9 @@ def exit_code(rc):
     return 128 - rc if rc < 0 else rc
 
 
-def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None, grace=10.0, poll=0.2):
-    """Starts `n` worker processes of the CLI (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
-    127.0.0.1) and supervises them: all children are polled together; as soon as one exits non-zero (signals included) the others
+def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None, grace=10.0, poll=0.2, script=None):
+    """Starts `n` worker processes of the CLI (`python -m module argv`; or of a script file, `python script argv`: bench.py launches
+    itself this way) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1, and supervises them: all children are polled together; as soon as one exits non-zero (signals included) the others
     -- which would otherwise sit in a collective until the RCCL timeout -- are terminated (SIGTERM, SIGKILL after `grace`
     seconds) and its code is returned (128 + N for signal N).  Returns 0 only if every rank returned 0.  The parent never
     touches the GPU."""
@@ -104,7 +104,8 @@ def spawn_ranks(n, argv, module="distdiff_amd.generate_data", env_extra=None, gr
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         env.update(env_extra or {})
-        procs.append(subprocess.Popen([sys.executable, "-m", module] + list(argv), env=env))
+        head = [sys.executable, script] if script else [sys.executable, "-m", module]
+        procs.append(subprocess.Popen(head + list(argv), env=env))
     failed = 0
     live = list(procs)
     try:

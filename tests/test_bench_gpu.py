@@ -29,12 +29,22 @@ def _check(line, steps, warmup):
 
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
-    _check(lines[0], 2, 1)
+    d = _check(lines[0], 2, 1)
+    assert d["config"]["shards"] == [[0, 0, 3 * d["config"]["images_per_step_per_gpu"]]] and "stub" not in d
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_this_box_has_gpus():
+    """`--gpus N` is honoured or refused, never ignored: on a box with fewer than 16 GPUs the plain entry point must say so (GPUs
+    counted from sysfs by the launcher parent, before any GPU call) instead of measuring one GPU and printing n_gpus 1."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "16", "--config", "tiny", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "GPU(s) are visible" in out.stderr and out.stdout.strip() == ""
 
 
 @pytest.mark.gpu

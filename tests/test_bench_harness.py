@@ -87,3 +87,61 @@ def test_bench_single_rank_needs_no_process_group():
     dt, out = bench.timed_steps(lambda i: seen.append(i) or i, 3, 1, lambda: None, lambda v: v)
     assert seen == [0, 1, 2, 3] and out == 3 and dt >= 0
     assert bench.job_rate(3, 32, 1, 2.0) == (96, 48.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# the real entry point: `python bench.py --gpus N` started plainly launches its own N ranks
+# ------------------------------------------------------------------------------------------------
+import json
+import subprocess
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run_bench(args, env_extra=None, drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_entry_point_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` (the form of the driver's recorded command) without torch.distributed.run around it: N ranks of the
+    same script under gloo with the stand-in engine (--harness_stub), ONE JSON line on stdout, n_gpus == N, one shard per rank that
+    together cover steps x B x N images, and the value is the whole job's."""
+    out = _run_bench(["--gpus", str(world), "--harness_stub", "--config", "tiny", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["stub"] is True and d["data"] == "stub"
+    assert "HARNESS STUB" in d["metric"]                       # cannot be mistaken for a measurement
+    per_rank = 4 * (3 + 1)
+    assert d["config"]["shards"] == [[r, r * per_rank, (r + 1) * per_rank] for r in range(world)]
+    assert abs(d["value"] - 3 * 4 * world / (d["ms_per_step"] * 3 / 1000.0)) < 1e-6 * d["value"]
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    """Under a launcher (RANK set) `--gpus` must equal WORLD_SIZE: a line with the wrong n_gpus is worse than no line."""
+    out = _run_bench(["--gpus", "8", "--harness_stub", "--config", "tiny"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and out.stdout.strip() == ""
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """No GPU call is needed to know: the launcher counts GPUs from the visibility variables / sysfs."""
+    out = _run_bench(["--gpus", "4", "--config", "tiny"], {"HIP_VISIBLE_DEVICES": "0,1"})
+    assert out.returncode != 0 and "2 GPU(s) are visible" in out.stderr and out.stdout.strip() == ""
+
+
+def test_resolve_world():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_world(None, {}) == (1, False)
+    assert bench.resolve_world(1, {}) == (1, False)
+    assert bench.resolve_world(8, {}) == (8, True)                                  # plain start: launch 8 ranks
+    assert bench.resolve_world(8, {"RANK": "3", "WORLD_SIZE": "8"}) == (8, False)     # torch.distributed.run / our own child
+    assert bench.resolve_world(None, {"RANK": "0", "WORLD_SIZE": "2"}) == (2, False)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {"RANK": "0", "WORLD_SIZE": "1"})
+    with pytest.raises(SystemExit):
+        bench.resolve_world(0, {})
