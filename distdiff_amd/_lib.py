@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DD_LIB") or os.path.join(_HERE, "libdistdiff_hip.so")   # DD_LIB: A/B builds for benchmarking
 
+ABI_VERSION = 6      # DD_ABI_VERSION of include/distdiff_hip.h this package's ctypes mirrors were written against
+
 _lib = None
 
 
@@ -31,6 +33,12 @@ def lib():
             _lib = C.CDLL(LIB_PATH)
         except OSError as e:  # missing libamdhip64 etc.
             raise DistDiffLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        # one version for both header surfaces (struct layouts and argument lists): a stale build must not be called with new mirrors
+        got = _lib.dd_abi_version() if hasattr(_lib, "dd_abi_version") else 5
+        if got != ABI_VERSION:
+            _lib = None
+            raise DistDiffLibraryError("%s was built as ABI version %d, this package speaks %d: rebuild with `python -m distdiff_amd.build`"
+                                       % (LIB_PATH, got, ABI_VERSION))
         _declare(_lib)
     return _lib
 
@@ -93,7 +101,7 @@ OPS_SYMBOLS = [
     "dd_debug_tensor", "dd_debug_num_tensors", "dd_debug_set_image", "dd_debug_set_images",
 ]
 ENGINE_SYMBOLS = [
-    "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
+    "dd_abi_version", "dd_create", "dd_destroy", "dd_last_error", "dd_load_tensor", "dd_finalize_weights", "dd_set_prototypes",
     "dd_set_schedule", "dd_add_noise", "dd_denoise_step", "dd_transform_guidance", "dd_direct_guidance", "dd_decode",
     "dd_expand", "dd_image_to_u8", "dd_guide_encode", "dd_guide_encode_pooled", "dd_unet_forward", "dd_unet_vjp", "dd_decode_vjp", "dd_guide_vjp",
     "dd_set_prompt", "dd_set_added_cond", "dd_vae_encode", "dd_text_encode", "dd_text_encode_tower", "dd_set_sample_weights", "dd_get_image_scores", "dd_declare_tensor", "dd_packed_bytes", "dd_export_packed", "dd_import_packed", "dd_profile_enable", "dd_profile_read", "dd_workspace_bytes", "dd_flops_last",

@@ -643,7 +643,9 @@ hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t strea
 }  // namespace
 
 // chunk split of the 8 x 8 level (M = 64 pixels x images: 64 tiles of 256 x 320 at 64 images -- a quarter of the chip): the smallest
-// power of two that gives >= 192 workgroups, every workgroup >= 2 chunks; 1 = this is not that case.  Needs the split-K scratch.
+// power of two that gives >= 192 workgroups -- halved until it DIVIDES the chunk count (the kernel hands ceil(chunks / split) chunks to
+// every blockIdx.y: with a remainder the last workgroups would start behind the last chunk; Cin = 2560 at 16 images: 16 -> 8) -- with
+// every workgroup >= 2 chunks; 1 = this is not that case.  Needs the split-K scratch.
 int conv_halo_split(const ConvGemmParams& p) {
   static const int on = getenv("DD_HALO_8X8") ? atoi(getenv("DD_HALO_8X8")) : 1;
   if (!on || p.Wo != 8 || p.Ho != 8 || p.H != 8 || p.W != 8 || p.shift || p.stride != 1 || (p.B & 3) || p.N % 320 || !p.partial) return 1;
@@ -651,7 +653,7 @@ int conv_halo_split(const ConvGemmParams& p) {
   const int tiles = (p.M / 256) * (p.N / 320), chunks = p.cin >> 6;
   int s = 1;
   while (tiles * s < 192 && s < 16) s *= 2;
-  if (s < 2 || chunks / s < 2) return 1;
+  while (s > 1 && (chunks % s || chunks / s < 2)) s >>= 1;
   return s;
 }
 
@@ -690,7 +692,7 @@ int conv_halo_config(const ConvGemmParams& p) {
     if (bm == 512 && !tall && p.N != 128) continue;
     if (tn == 2 && p.N % 320 == 0) continue;            // 320-multiples: 160-wide tiles
     HaloGeo g;
-    if (!halo_geometry(p, bm, &g)) continue;
+    if (!halo_geometry(p, bm, &g) || g.ipt > 1) continue;   // multi-image tiles (8 x 8) exist in the chunk-split form only (above)
     if ((p.M / bm) * (p.N / bn) < 192) continue;        // needs (most of) the chip: small grids keep the split-K forms
     if (2 * bn * 128 + ((g.halo_px + 7) & ~7) * 128 + bn * 4 + 512 + 64 > 163840) continue;
     return tn;
@@ -746,6 +748,6 @@ hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream)
   HaloGeo g;
   if (!halo_geometry(p, tn == 2 || tn == 6 || tn == 1 ? 512 : 256, &g)) return hipErrorInvalidValue;
   if (tn == 1) return run_halo<1, 2>(p, g, stream);
-  if (g.ipt > 1) return (tn == 5 && p.ksplit > 1) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
+  if (g.ipt > 1) return (tn == 5 && p.ksplit > 1 && (p.cin >> 6) % p.ksplit == 0) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
   return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

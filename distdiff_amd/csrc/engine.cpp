@@ -148,6 +148,8 @@ void guided_backward(dd_engine* E, int k, int step_index, const float* g_znext, 
 
 void set_config_defaults(dd_config& c) {
   if (c.max_guidance_period < 1) c.max_guidance_period = 1;
+  // same-binary A/B from the environment (tools/, bench.py --config sdxl); an engine built with the field set does not need it
+  if (!c.unet_attn_fp8 && getenv("DD_ATTN_FP8")) c.unet_attn_fp8 = atoi(getenv("DD_ATTN_FP8")) != 0;
 }
 
 }  // namespace
@@ -161,8 +163,15 @@ void set_config_defaults(dd_config& c) {
 
 extern "C" {
 
+int dd_abi_version(void) { return DD_ABI_VERSION; }
+
 int dd_create(const dd_config* cfg, dd_engine** out) {
   if (!cfg || !out) return DD_ERR_ARG;
+  if (cfg->abi_version != DD_ABI_VERSION) {
+    fprintf(stderr, "dd_create: dd_config.abi_version %d, library built as %d (caller compiled against another include/distdiff_hip.h?)\n",
+            cfg->abi_version, DD_ABI_VERSION);
+    return DD_ERR_ARG;
+  }
   if (cfg->unet_levels > DD_MAX_LEVELS || cfg->vae_levels > DD_MAX_LEVELS || cfg->guide_stages > DD_MAX_LEVELS || cfg->max_batch < 1)
     return DD_ERR_ARG;
   dd_engine* e = new dd_engine();

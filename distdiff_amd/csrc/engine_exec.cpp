@@ -204,10 +204,7 @@ void run_fwd(const Program& P, const Ctx& c, int op_begin, int op_end) {
         p.o = act_ptr(c, y); p.ldo = y.ld; p.lse = (float*)(c.act + op.stats_off);
         p.B = q.B; p.H = op.heads; p.Nq = op.Nq; p.Nk = op.Nk; p.D = op.D; p.scale = op.q_prescaled ? 0.6931471805599453f : 1.f / sqrtf((float)op.D); p.q_prescaled = op.q_prescaled;
         p.causal = op.causal;
-        {  // BASELINE configs[4]: fp8 P.V for d = 64 heads (SDXL), opt-in
-          static const int fp8 = getenv("DD_ATTN_FP8") ? atoi(getenv("DD_ATTN_FP8")) : 0;
-          p.pv_fp8 = fp8 && op.D == 64 && !op.causal;
-        }
+        p.pv_fp8 = op.pv_fp8;      // BASELINE configs[4]: fp8 P.V for d = 64 heads (SDXL), opt-in per engine (dd_config.unet_attn_fp8)
         if (op.cross_slot < 0 && attention_gemm_supported(p) && c.tap1x1 && attention_gemm_workspace(p.Nq, p.Nk, p.D, 0) <= c.tmp_cap)
           HIPCHK(launch_attention_gemm_fwd(p, c.scratch_tmp, c.tmp_cap, c.tap1x1, (float*)c.scratch_partial, c.partial_cap, c.s));
         else

@@ -467,7 +467,9 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
                                       qs ? C : 0, qscale));
     if (fold) b.fold_ln();
     int q = P.view(qkv, 0, C), k = P.view(qkv, C, C), v = P.view(qkv, 2 * C, C);
+    const int fp8 = E->cfg.unet_attn_fp8 && C / heads == 64;      // BASELINE configs[4]: fp8 P.V for the d = 64 heads (SDXL)
     int a = b.attn(q, k, v, heads, HW, HW, -1, 0, qs);
+    P.ops.back().pv_fp8 = fp8;
     h = b.conv(a, make_conv(E, m, t + ".attn1.to_out.0", 0), 1, 0, h);
     // cross attention: K,V of the text embeddings are computed once per prompt (dd_set_prompt)
     n = b.ln(h, make_norm(E, m, t + ".norm2"), 1e-5f);
@@ -486,6 +488,7 @@ int build_transformer(Builder& b, const std::string& p, int x, int heads, int G,
     slot.C = C;
     E->cross_slots.push_back(slot);
     a = b.attn(q2, -1, -1, heads, HW, E->cfg.text_len, (int)E->cross_slots.size() - 1, 0, qs);
+    P.ops.back().pv_fp8 = fp8;
     h = b.conv(a, make_conv(E, m, t + ".attn2.to_out.0", 0), 1, 0, h);
     // GEGLU feed-forward
     n = b.ln(h, make_norm(E, m, t + ".norm3"), 1e-5f);

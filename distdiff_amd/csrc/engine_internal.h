@@ -102,6 +102,7 @@ struct Op {
   int G = 0, silu = 0; float eps = 0;
   int heads = 0, D = 0, Nq = 0, Nk = 0, cross_slot = -1;
   int causal = 0, act_kind = 0;
+  int pv_fp8 = 0;              // OP_ATTN: P.V on the fp8 MFMA (dd_config.unet_attn_fp8; d = 64 heads of the UNet only)
   int q_prescaled = 0;         // OP_ATTN: the to_q weights carry 1/sqrt(D) * log2(e) (attn_prescale(); the kernels then get scale = ln 2)
   int patch = 0, sel_stride = 0;   // OP_PATCHIFY: patch size; OP_SELECT: row stride (tokens per image)
   size_t stats_off = 0;  // fp32 stats / lse in the activation slab

@@ -34,6 +34,7 @@ class DDConfig(C.Structure):
         ("guide_feature_dim", C.c_int),
         ("unet_transformer_depth", _IA), ("unet_level_heads", _IA), ("unet_add_time_dim", C.c_int), ("unet_add_text_dim", C.c_int),
         ("text_hidden_layer", C.c_int), ("text2_heads", C.c_int), ("text2_act", C.c_int), ("text2_eps", C.c_float),
+        ("unet_attn_fp8", C.c_int), ("abi_version", C.c_int),
     ]
 
 
@@ -51,6 +52,7 @@ class DDExpandArgs(C.Structure):
 
 def _declare(l):
     i, f = C.c_int, C.c_float
+    l.dd_abi_version.argtypes = []
     l.dd_create.argtypes = [C.POINTER(DDConfig), C.POINTER(vp)]
     l.dd_destroy.argtypes = [vp]
     l.dd_destroy.restype = None
@@ -97,8 +99,13 @@ def _declare(l):
     l.dd_flops_last.restype = C.c_double
 
 
-def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period):
+DD_ABI_VERSION = _lib.ABI_VERSION      # include/distdiff_hip.h
+
+
+def _to_c_config(cfg: EngineConfig, enable_grad, max_guidance_period, attn_fp8=False):
     c = DDConfig()
+    c.abi_version = DD_ABI_VERSION
+    c.unet_attn_fp8 = int(bool(attn_fp8))
     u, v, g = cfg.unet, cfg.vae, cfg.guide
 
     def arr(xs):
@@ -170,8 +177,9 @@ def batch_for_free_hbm(free_bytes, guided=True):
 class Engine:
     """One engine per device. Mirrors the objects the reference builds at generate_data.py:863-922, 1100-1125."""
 
-    def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0", layout=None):
-        """weights: {"unet" | "vae" | "guide" | "text" | "text2": state dict} -- packed on this rank; or None with `layout` = the
+    def __init__(self, cfg: EngineConfig, weights, enable_grad=True, max_guidance_period=2, device="cuda:0", layout=None, attn_fp8=False):
+        """attn_fp8: BASELINE configs[4]'s fp8 MFMA attention (P.V of the UNet's d = 64 heads in e4m3; dd_config.unet_attn_fp8).
+        weights: {"unet" | "vae" | "guide" | "text" | "text2": state dict} -- packed on this rank; or None with `layout` = the
         `weight_layout()` of the rank that has them: the engine is then built from the tensor shapes alone and its packed weight
         buffers are filled by `import_packed` (launcher.broadcast_packed_weights: one RCCL broadcast of the packed device buffers
         instead of every process loading its own copy, scripts/exps/expand_diff.sh:19-24)."""
@@ -180,7 +188,7 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.L = _lib.lib()
         self._h = vp()
-        cc = _to_c_config(cfg, enable_grad, max_guidance_period)
+        cc = _to_c_config(cfg, enable_grad, max_guidance_period, attn_fp8)
         self._chk(self.L.dd_create(C.byref(cc), C.byref(self._h)), "dd_create")
         if weights is not None:
             self.layout = []

@@ -95,8 +95,11 @@ def parse_args(argv=None):
     p.add_argument("--synthetic_arch", default="sd15", choices=["sd15", "sdxl"],
                    help="with --synthetic: the SD-1.x structure or the SDXL-base one (two text towers, text_time conditioning; BASELINE "
                    "configs[4]).  A real model directory is recognised by its text_encoder_2/ sub-folder")
-    p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = the largest of 32 / 16 / 8 whose workspace fits the free HBM: 239 / 122 / 65 GB with transform "
-                   "guidance at 512x512, 32 being 4 %% faster than 16 and 16 12 %% faster than 8); units (image, expand index) are independent")
+    p.add_argument("--engine_batch", type=int, default=0, help="images per engine launch (0 = the largest of 32 / 16 / 8 whose workspace fits the free HBM -- engine.batch_for_free_hbm: "
+                   "about 5.85 GB per image with transform guidance at 512x512 + 12 GB, i.e. 199 / 106 / 59 GB; 32 is 4 %% faster than 16 and 16 12 %% "
+                   "faster than 8; SDXL at 1024x1024: 4 or 2 --, the minimum over the ranks of a run); units (image, expand index) are independent")
+    p.add_argument("--attn_fp8", action="store_true", help="BASELINE configs[4]: P.V of the UNet's d = 64 attention heads (SDXL) on the fp8 MFMA "
+                   "(dd_config.unet_attn_fp8).  Off by default: the bf16 form is faster on MI355X and closer to fp32 (DESIGN.md Appendix A row 28)")
     p.add_argument("--data_root", type=str, default="data")
     p.add_argument("--gpus", type=int, default=1, help="spawn this many ranks (one per GPU) that shard the images like --total_split; "
                    "weights are loaded once on rank 0 and broadcast over RCCL")
@@ -409,20 +412,22 @@ def auto_engine_batch(args, dev, distributed=False):
     186.7 GB measured at 32 images; 32 images per launch are 4 % faster than 16 on an MI355X); 16 otherwise.  Ranks of one run agree on the minimum."""
     if args.tiny:
         return 8
+    on_gpu = torch.device(dev).type == "cuda" and torch.cuda.is_available()
     if args.synthetic_arch == "sdxl" or os.path.isdir(os.path.join(args.pretrained_model_name_or_path, "text_encoder_2")):
         # SDXL-base at 1024 x 1024: 161 GB at 4 images, 115 GB at 2 (bench.py --config sdxl)
-        if torch.device(dev).type == "cuda" and torch.cuda.is_available():
-            return 4 if torch.cuda.mem_get_info(torch.device(dev))[0] >= 175e9 else 2
-        return 2
-    B = 16
-    if args.resolution == 512 and torch.device(dev).type == "cuda" and torch.cuda.is_available():
+        B = (4 if torch.cuda.mem_get_info(torch.device(dev))[0] >= 175e9 else 2) if on_gpu else 2
+    elif args.resolution == 512 and on_gpu:
         from .engine import batch_for_free_hbm
         B = batch_for_free_hbm(torch.cuda.mem_get_info(torch.device(dev))[0], guided=bool(args.guidance_type))
-        if distributed:
-            import torch.distributed as dist
-            t = torch.tensor([B], dtype=torch.int64, device=torch.device(dev))
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            B = int(t.item())
+    else:
+        return 16
+    if distributed and on_gpu:
+        # rank 0's configuration (max_batch included) is what every rank builds its engine from (build_engine_distributed): the batch
+        # must fit the rank with the LEAST free HBM, and every rank's loop must pack the same EB
+        import torch.distributed as dist
+        t = torch.tensor([B], dtype=torch.int64, device=torch.device(dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        B = int(t.item())
     return B
 
 
@@ -436,7 +441,7 @@ def build_engine(args, device=None, distributed=False):
     stash = max(1, args.guidance_period) if args.guidance_type == "transform_guidance" else 1
 
     def make_engine(cfg, weights, layout):
-        return Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=dev, layout=layout)
+        return Engine(cfg, weights, enable_grad=guided, max_guidance_period=stash, device=dev, layout=layout, attn_fp8=args.attn_fp8)
 
     if distributed:
         # rank 0 loads + packs once; the packed device buffers go to the other ranks in one RCCL broadcast (launcher.py)

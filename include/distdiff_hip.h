@@ -43,6 +43,13 @@ enum dd_status { DD_OK = 0, DD_ERR_ARG = -1, DD_ERR_HIP = -2, DD_ERR_STATE = -3,
 
 #define DD_MAX_LEVELS 8
 
+/* Layout version of the structs and argument lists of this header and distdiff_hip_ops.h.  A caller sets dd_config.abi_version =
+ * DD_ABI_VERSION (after zero-initialising the struct: every struct of this ABI must be zero-initialised, new fields are appended and
+ * mean "off" at 0); dd_create refuses another value with DD_ERR_ARG, and dd_abi_version() tells what the loaded library was built
+ * as.  6: dd_config gained unet_attn_fp8 + abi_version; 5 (unversioned): workspace_bytes in the dd_op_attention_gemm_* lists,
+ * ConvGemmParams.wgroup_rows / wgroup_elems, AttnParams.pv_fp8. */
+#define DD_ABI_VERSION 6
+
 typedef struct dd_config {
   /* UNet2DConditionModel (unet/config.json) */
   int unet_in_channels, unet_out_channels, unet_levels;
@@ -91,6 +98,11 @@ typedef struct dd_config {
   int text2_heads;        /* second tower (loaded under model "text2"): num_attention_heads (0: 20) */
   int text2_act;          /* 0 quick_gelu, 1 gelu (SDXL: gelu) */
   float text2_eps;        /* layer_norm_eps (0: 1e-5) */
+  /* BASELINE.json configs[4] "fp8 MFMA attention": 1 = the UNet's d = 64 heads (SDXL) run P.V on the block-scaled fp8 MFMA (e4m3
+   * probabilities and values, fp32 accumulation; QK^T, softmax and LSE as in the bf16 form).  Per engine, so both forms can live in one
+   * process.  0 = bf16 (the default: faster on MI355X). */
+  int unet_attn_fp8;
+  int abi_version;        /* must be DD_ABI_VERSION */
 } dd_config;
 
 typedef struct dd_sampler_params {
@@ -117,7 +129,8 @@ typedef struct dd_expand_args {
   float* score_out;           /* [1] device scalar: last guidance score (may be NULL) */
 } dd_expand_args;
 
-int dd_create(const dd_config* cfg, dd_engine** out);
+int dd_abi_version(void);                     /* DD_ABI_VERSION the library was built with */
+int dd_create(const dd_config* cfg, dd_engine** out);   /* DD_ERR_ARG when cfg->abi_version != DD_ABI_VERSION */
 void dd_destroy(dd_engine* e);
 const char* dd_last_error(dd_engine* e);
 

@@ -94,3 +94,20 @@ def test_weight_packing_host_side():
     ref = w.to(torch.bfloat16).float().permute(1, 2, 3, 0).reshape(3, 9, 5)
     assert torch.equal(got, ref)
     assert [((t >> 6) & 63) - 32 for t in tt] == [1, 1, 1, 0, 0, 0, -1, -1, -1]
+
+
+def test_abi_version_is_checked():
+    """include/distdiff_hip.h DD_ABI_VERSION == what the library reports == what the ctypes mirrors speak; dd_create refuses a config block
+    whose abi_version field is anything else (a caller compiled against an older header passes 0 or garbage there).  No GPU call."""
+    from distdiff_amd import _lib, engine
+    lib = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "distdiff_hip.h")).read()
+    ver = int(re.search(r"#define\s+DD_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.dd_abi_version() == ver == _lib.ABI_VERSION == engine.DD_ABI_VERSION
+    cfg = engine.DDConfig()
+    cfg.max_batch = 1
+    h = ctypes.c_void_p()
+    assert lib.dd_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and not h.value          # DD_ERR_ARG: abi_version 0
+    cfg.abi_version = ver
+    assert lib.dd_create(ctypes.byref(cfg), ctypes.byref(h)) == 0 and h.value
+    lib.dd_destroy(h)

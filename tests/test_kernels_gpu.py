@@ -78,6 +78,11 @@ CONV_CASES = [
     # 64-channel chunks into fp32 partial sums + the reduce kernel (4-way at 64 images, 8-way at 32), forward and input-gradient
     ("halo_8x8_multi_image_split4", 64, 1280, 1280, 8, 8, 3, 1, 1, 0),
     ("halo_8x8_cin2560_split8", 32, 2560, 1280, 8, 8, 3, 1, 1, 0),
+    # 16 images (the automatic batch of a small-HBM device): 16 tiles want a 16-way split, 40 chunks do not divide by 16 -> 8-way
+    ("halo_8x8_cin2560_b16_split_divides_chunks", 16, 2560, 1280, 8, 8, 3, 1, 1, 0),
+    # >= 192 tiles at 8 x 8 (--resolution 256 with a large engine batch, or an ABI caller): no chunk split, so no multi-image halo form --
+    # the general kernels take it (was: hipErrorInvalidValue from the halo launcher)
+    ("8x8_many_tiles_no_split", 192, 128, 1280, 8, 8, 3, 1, 1, 0),
     # N <= 4 (conv_out of the decoder 128 -> 3 and of the UNet 320 -> 4): the small kernel's 256 x 64 tiles
     ("n3_vae_conv_out", 1, 128, 3, 256, 256, 3, 1, 1, 0),
     ("n4_unet_conv_out", 16, 320, 4, 64, 64, 3, 1, 1, 0),
