@@ -75,7 +75,8 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int), ("scale", C.c_float),
                 ("d_o", vp), ("lddo", C.c_int), ("dq", vp), ("dk", vp), ("dv", vp),
-                ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("delta", vp), ("q_prescaled", C.c_int), ("causal", C.c_int), ("pv_fp8", C.c_int)]
+                ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("delta", vp), ("q_prescaled", C.c_int), ("causal", C.c_int), ("pv_fp8", C.c_int),
+                ("no_shortk", C.c_int)]
 
 
 class ConvF32Params(C.Structure):

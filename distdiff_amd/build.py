@@ -12,8 +12,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "_obj")
-LIB = os.path.join(HERE, "libdistdiff_hip.so")
+# DD_BUILD_OBJ / DD_BUILD_LIB: a variant build beside the product one (A/B of compile-time switches: DD_EXTRA_CFLAGS=-D... ; run with DD_LIB=)
+OBJ = os.environ.get("DD_BUILD_OBJ") or os.path.join(HERE, "csrc", "_obj")
+LIB = os.environ.get("DD_BUILD_LIB") or os.path.join(HERE, "libdistdiff_hip.so")
 SOURCES = ["conv_gemm.hip", "conv_gemm2.hip", "conv_halo.hip", "gemm_ws.hip", "norm.hip", "attention.hip", "attention_shortk.hip", "attention_gemm.hip", "elementwise.hip", "guide_f32.hip", "weights.cpp", "ops_abi.cpp",
            "engine_weights.cpp", "engine_graph.cpp", "engine_exec.cpp", "engine.cpp"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs. With the default heuristic the attention kernels put them in AccVGPRs

@@ -285,7 +285,7 @@ hipError_t run_shortk(const AttnParams& p, hipStream_t s) {
 // Eligible: non-causal, <= 80 keys, whole 32-query tiles, d in {40, 64, 80}, rows within the 32-bit byte offsets of one image
 bool attention_shortk_supported(const AttnParams& p) {
   static const int on = getenv("DD_ATTN_SHORTK") ? atoi(getenv("DD_ATTN_SHORTK")) : 1;
-  if (!on || p.causal || p.pv_fp8 || p.Nk < 1 || p.Nk > 80 || (p.Nq & 31) || p.Nq < 32) return false;
+  if (!on || p.no_shortk || p.causal || p.pv_fp8 || p.Nk < 1 || p.Nk > 80 || (p.Nq & 31) || p.Nq < 32) return false;
   if (p.D != 40 && p.D != 64 && p.D != 80) return false;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return false;
   if ((size_t)p.Nq * (size_t)p.ldq * 2 >= 0xF0000000ull || (size_t)p.Nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 >= 0xF0000000ull) return false;

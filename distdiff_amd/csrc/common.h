@@ -48,7 +48,32 @@ __device__ __forceinline__ float erf_as(float x) {
   const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
   return copysignf(__builtin_fmaf(-p * t, e, 1.f), x);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
+// GELU for the GEGLU epilogues WITHOUT transcendentals: gelu(x) = x * Phi(x), Phi(x) ~ 0.5 + t * P(t^2) with t = clamp(x, -4.5, 4.5) and P
+// the degree-9 minimax polynomial (10 coefficients, fitted by linear programming under the constraint Phi~(4.5) = 1, so that the
+// clamped ends are exactly 0 / 1).  13 full-rate VALU (v_med3, v_mul, 9 v_fma, v_fma, v_mul) instead of ~20 + v_rcp + v_exp: the K = 320
+// GEGLU projection is bound by the vector issue port (an MFMA holds it for 8 of its 16 cycles, MI355X guide), not by the matrix pipe.
+// Accuracy (tests/test_oracle.py::test_gelu_polynomial, evaluated in fp32 from THESE literals): |gelu~ - gelu| <= 5e-5 everywhere,
+// relative error <= 1.2e-5 for x > 0 and <= 1e-4 for x > -2; beyond -3 the value itself is < 4e-3 and only the absolute bound holds.
+// One bf16 rounding of the product is 2e-3 relative: 0.1 / 0.4 / 6.8 % of the bf16 outputs differ from the rounded exact product for
+// gate pre-activations of sigma 0.5 / 1 / 2 (A&S form above: 0.003 / 0.009 / 1.4 %), by one ulp except in the tail.
+#define DD_GELU_CLAMP 4.5f
+#define DD_GELU_POLY { 3.989228904e-01f, -6.641460210e-02f, 9.885823354e-03f, -1.140101929e-03f, 1.011194836e-04f, \
+                       -6.729636425e-06f, 3.209943316e-07f, -1.023312812e-08f, 1.934523375e-10f, -1.629367648e-12f }
+__device__ __forceinline__ float gelu_poly_f(float x) {
+  constexpr float c[10] = DD_GELU_POLY;
+  const float t = __builtin_amdgcn_fmed3f(x, -DD_GELU_CLAMP, DD_GELU_CLAMP);
+  const float u = t * t;
+  float p = c[9];
+#pragma unroll
+  for (int k = 8; k >= 0; --k) p = __builtin_fmaf(p, u, c[k]);
+  return x * __builtin_fmaf(t, p, 0.5f);
+}
+#ifdef DD_GELU_ERF_AS      // A/B build: the rcp + exp2 form in the epilogues
+__device__ __forceinline__ float gelu_f(float x) { return gelu_erf_f(x); }
+#else
+__device__ __forceinline__ float gelu_f(float x) { return gelu_poly_f(x); }
+#endif
 __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }

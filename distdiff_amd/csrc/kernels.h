@@ -144,6 +144,7 @@ struct AttnParams {
   int q_prescaled;                          // Q already carries 1/sqrt(D) * log2(e) (folded into the to_q weights): scores are log2-domain; pass scale = ln 2
   int causal;                               // forward only: key j visible to query i iff j <= i (CLIP text encoder)
   int pv_fp8;                               // forward only, D = 64: P.V on the block-scaled fp8 MFMA (e4m3 probabilities and values)
+  int no_shortk;                            // diagnostics: keep <= 80-key launches on the streaming forward (accuracy A/B inside one process)
 };
 hipError_t launch_attention_fwd(const AttnParams& p, hipStream_t stream);
 hipError_t launch_attention_bwd(const AttnParams& p, hipStream_t stream);

@@ -217,7 +217,12 @@ def save_png(img, path):
 
 class AsyncPNGWriter:
     """Output stage: quantise on the GPU, copy device->pinned host asynchronously, encode PNGs on a thread
-    pool, so the next batch's kernels are enqueued while the previous batch is read back and encoded."""
+    pool.  `submit` never waits for the batch it is given: the uint8 conversion, the device->host copies and an event are enqueued
+    behind that batch's kernels, and the host goes on to prepare and enqueue the NEXT batch; what it waits for is the event of the
+    batch before -- finished long ago -- whose images then go to the writer threads while the GPU runs the batch just enqueued.
+    The host is thus exactly one batch ahead and the GPU never idles between batches.  Pinned host buffers are a small ring, reused
+    once the PNG jobs reading them are done (a pinned allocation per batch costs milliseconds of host time)."""
+    RING = 3
 
     def __init__(self, engine, writer=save_png, threads=None):
         if not threads:      # the launcher sets DD_PNG_THREADS for its ranks; a plain single-process run takes the same function's answer
@@ -227,26 +232,59 @@ class AsyncPNGWriter:
         self.engine, self.writer = engine, writer
         self.pool = ThreadPoolExecutor(max_workers=threads)
         self.pending = None
+        self.ring = []          # [pinned buffer, futures of the PNG jobs reading it]
         self.futures = []
         self.written = 0
 
-    def submit(self, img_dev, paths):
+    def _host_buffer(self, shape):
+        """A pinned uint8 buffer of at least `shape` none of whose PNG jobs is still running (oldest first; allocates up to RING)."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        for slot in self.ring:
+            if slot[0].numel() >= n and all(f.done() for f in slot[1]) and not slot[2]:
+                slot[1], slot[2] = [], True
+                return slot
+        if len(self.ring) < self.RING:
+            slot = [torch.empty(n, dtype=torch.uint8, pin_memory=True), [], True]
+            self.ring.append(slot)
+            return slot
+        slot = next(s for s in self.ring if not s[2] and s[0].numel() >= n)      # all busy: wait for the oldest one's jobs
+        for f in slot[1]:
+            f.result()
+        slot[1], slot[2] = [], True
+        return slot
+
+    def submit(self, img_dev, paths, scores_dev=None, after=None):
+        """img_dev [n,3,H,W] fp32 on the device (n = len(paths)); scores_dev: a small device tensor read back with the images;
+        after(scores_host or None): called on the host once this batch has arrived (one submit later, or at close)."""
         u8 = self.engine.image_to_u8(img_dev)
-        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        slot = self._host_buffer(u8.shape)
+        host = slot[0][:u8.numel()].view(u8.shape)
         host.copy_(u8, non_blocking=True)
+        sc_host = None
+        if scores_dev is not None:
+            sc_host = torch.empty(scores_dev.shape, dtype=scores_dev.dtype, pin_memory=True)
+            sc_host.copy_(scores_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        prev, self.pending = self.pending, (ev, host, paths, u8)
+        prev, self.pending = self.pending, (ev, slot, host, paths, (u8, img_dev, scores_dev), sc_host, after)
         self._drain(prev)
 
     def _drain(self, item):
         if item is None:
             return
-        ev, host, paths, _keep = item
+        ev, slot, host, paths, _keep, sc_host, after = item
         ev.synchronize()
         for k, p in enumerate(paths):
-            self.futures.append(self.pool.submit(self.writer, host[k].numpy(), p))
+            f = self.pool.submit(self.writer, host[k].numpy(), p)
+            slot[1].append(f)
+            self.futures.append(f)
             self.written += 1
+        slot[2] = False         # in flight on the writer threads only: reusable once they are done
+        if after is not None:
+            after(sc_host)
+        self.futures = [f for f in self.futures if not f.done() or f.exception() is not None]
 
     def close(self):
         self._drain(self.pending)
@@ -348,17 +386,23 @@ def run_expansion(args, engine, sched, ds, writer=save_png, rng_device="cpu"):
         if args.guidance_type and hasattr(engine, "set_sample_weights"):
             engine.set_sample_weights([1.0 / u[3] for u in chunk] + [0.0] * (EB - nb))
         z, img, score = engine.expand(lat, noise, e, b, tg, si, args.guidance_type or None, gfirst, gcount, want_image=True)
-        if args.guidance_type:
-            per_image = engine.image_scores().cpu().tolist() if hasattr(engine, "image_scores") else [float(score)] * EB
+
+        def log_scores(per_image, chunk=chunk):
             for u, sc in zip(chunk, per_image):
                 acc = group_scores.setdefault(u[2], [])
                 acc.append(sc)
                 if len(acc) == u[3]:                                          # the reference's log line (:1208-1216), one per batch
                     log.info("%s at t=%d for %d steps, score: %.4f", args.guidance_type, ts[gfirst], gcount, sum(acc) / len(acc))
                     del group_scores[u[2]]
+
         if async_writer is not None:
-            async_writer.submit(img[:nb], paths)
+            # nothing here waits for this batch: images and scores are read back behind its kernels, the log lines and the PNG jobs
+            # follow one batch later (AsyncPNGWriter), and the host goes on to enqueue the next batch
+            sc_dev = engine.image_scores() if args.guidance_type and hasattr(engine, "image_scores") else None
+            async_writer.submit(img[:nb], paths, sc_dev, (lambda h: log_scores(h.tolist())) if sc_dev is not None else None)
         else:
+            if args.guidance_type:
+                log_scores(engine.image_scores().cpu().tolist() if hasattr(engine, "image_scores") else [float(score)] * EB)
             for k in range(nb):
                 writer(img[k], paths[k])
                 written += 1

@@ -265,7 +265,7 @@ def attention_gemm(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, ws_images=8):
     return o, lse, dq, dk, dv
 
 
-def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False, q_prescaled=False, pv_fp8=False):
+def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=False, q_prescaled=False, pv_fp8=False, no_shortk=False):
     """q [B*Nq, >=H*D], k/v [B*Nk, >=H*D] bf16 (row strides taken from the tensors).  q_prescaled: q already carries
     1/sqrt(D) * log2(e) (the engine folds it into the to_q weights); pass scale = ln 2 then.  pv_fp8 (D = 64, forward): the P.V product
     on the block-scaled fp8 MFMA (e4m3 probabilities and values)."""
@@ -279,6 +279,7 @@ def attention(q, k, v, B, H, Nq, Nk, D, scale, d_o=None, need_dkv=True, causal=F
     p.causal = 1 if causal else 0
     p.q_prescaled = 1 if q_prescaled else 0
     p.pv_fp8 = 1 if pv_fp8 else 0
+    p.no_shortk = 1 if no_shortk else 0       # diagnostics: <= 80 keys on the streaming kernel (accuracy A/B)
     check(L.dd_op_attention_fwd(C.byref(p), _stream()), "attn_fwd")
     if d_o is None:
         return o, lse

@@ -581,6 +581,33 @@ def test_attention_short_keys(ops, case):
     assert_close(dq.reshape(B, Nq, H, D), gq, rtol=3e-2, atol=3e-3, what=name + " dQ")
 
 
+def test_short_key_kernel_is_as_accurate_as_the_streaming_kernel(ops):
+    """The default cross-attention kernel (attention_shortk.hip, d = 40 with the row sums from a ones column) against the streaming forward
+    it replaced (AttnParams.no_shortk) ON THE SAME INPUTS, both against fp32 softmax: O rel-L2 and the LSE error of the short-key kernel must
+    not exceed the streaming kernel's by more than 5 % -- so the looser own-forward bound of tests/test_fullsize_gpu.py (conditioning of the
+    guide's masks) cannot hide an accuracy regression of the kernel itself."""
+    B, H, Nq, Nk, D = 2, 8, 4096, 77, 40
+    g = torch.Generator().manual_seed(5)
+    for gain in (1.0, 2.0):
+        q = bf(torch.randn(B, Nq, H, D, generator=g) * gain * (1.4426950408889634 / math.sqrt(D)))       # prescaled, as the engine's to_q emits it
+        k = bf(torch.randn(B, Nk, H, D, generator=g) * gain)
+        v = bf(torch.randn(B, Nk, H, D, generator=g))
+        s = torch.einsum("bqhd,bkhd->bhqk", q, k) * 0.6931471805599453
+        ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+        ref_lse = torch.logsumexp(s, dim=-1)
+        dev = lambda t, n: t.reshape(B * n, H * D).to(torch.bfloat16).cuda()
+        err = {}
+        for name, off in (("shortk", False), ("stream", True)):
+            o, lse = ops.attention(dev(q, Nq), dev(k, Nk), dev(v, Nk), B, H, Nq, Nk, D, 0.6931471805599453, q_prescaled=True, no_shortk=off)
+            torch.cuda.synchronize()
+            e = o.float().cpu().reshape(B, Nq, H, D) - ref
+            err[name] = (float(e.norm() / ref.norm()), float((lse.cpu() - ref_lse).abs().max()))
+        print("cross-attention 77 keys d=40 gain %.0f: O rel-L2 short-key %.5f streaming %.5f | LSE max err %.5f / %.5f"
+              % (gain, err["shortk"][0], err["stream"][0], err["shortk"][1], err["stream"][1]))
+        assert err["shortk"][0] != err["stream"][0], "AttnParams.no_shortk did not select another kernel"
+        assert err["shortk"][0] <= 1.05 * err["stream"][0] and err["shortk"][1] <= 1.05 * err["stream"][1] + 1e-4, err
+
+
 PRE_CASES = [("self_d40", 2, 8, 512, 512, 40, 1.0), ("self_d40_peaky", 1, 8, 1024, 2048, 40, 2.0), ("cross77_d40", 2, 8, 256, 77, 40, 1.0),
              ("self_d64", 1, 2, 200, 200, 64, 1.5), ("self_d80", 1, 4, 256, 320, 80, 1.5), ("self_d160", 1, 2, 64, 64, 160, 1.0),
              # fewer keys than one 64-key tile (the tiny config's 4x4 / 8x8 levels and its 13-token prompt): the first tile is also the ragged one

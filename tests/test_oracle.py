@@ -309,3 +309,34 @@ def test_reduced_precision_floor_of_the_oracle_loop():
     assert out["fp16"][0] < 0.01 and out["fp16"][1] > 52.0 and out["fp16"][4] < 1e-4
     assert out["bf16"][0] < 0.08 and out["bf16"][1] > 35.0 and out["bf16"][4] < 2e-3
     assert out["fp16"][0] < out["bf16"][0] and out["fp16"][2] < out["bf16"][2]
+
+
+def test_gelu_polynomial():
+    """The transcendental-free GELU of the GEGLU epilogues (distdiff_amd/csrc/common.h: gelu_poly_f): the literals are read from the
+    header and evaluated here exactly as the kernel does (fp32 Horner with fused multiply-adds, clamp at +-DD_GELU_CLAMP) against
+    x * Phi(x) in float64 -- diffusers' GEGLU is `hidden * F.gelu(gate)` with the erf form.  Stated accuracy:
+    absolute <= 5e-5 everywhere, relative <= 1.2e-5 for x > 0, <= 1e-4 for x > -2, Phi~ stays inside [0, 1] to 2e-6."""
+    import re
+    import numpy as np
+    from scipy.special import ndtr
+    src = open(os.path.join(os.path.dirname(__file__), "..", "distdiff_amd", "csrc", "common.h")).read()
+    clamp = np.float32(re.search(r"#define\s+DD_GELU_CLAMP\s+([0-9.]+)f", src).group(1))
+    body = re.search(r"#define\s+DD_GELU_POLY\s*\{(.*?)\}", src, re.S).group(1).replace("\\", " ")
+    c = np.array([float(v.strip().rstrip("f")) for v in body.split(",")], dtype=np.float32)
+    assert len(c) == 10 and clamp == np.float32(4.5)
+    x = np.linspace(-12, 12, 2_400_001).astype(np.float32)
+    t = np.clip(x, -clamp, clamp)
+    u = (t * t).astype(np.float32)
+    p = np.full_like(u, c[9])
+    for k in range(8, -1, -1):
+        p = (p.astype(np.float64) * u + c[k]).astype(np.float32)              # one rounding per step: fma
+    phi = (t.astype(np.float64) * p + 0.5).astype(np.float32)
+    g = (x * phi).astype(np.float32)
+    xd = x.astype(np.float64)
+    ref = xd * ndtr(xd)
+    err = np.abs(g - ref)
+    rel = err / np.maximum(np.abs(ref), 1e-300)
+    assert err.max() <= 5e-5, err.max()
+    assert rel[x > 1e-3].max() <= 1.2e-5 and rel[(x > -2) & (np.abs(x) > 1e-3)].max() <= 1e-4
+    assert phi.min() >= -2e-6 and phi.max() <= 1 + 2e-6
+    assert np.all(phi[x >= clamp] == phi[x >= clamp][0]) and abs(float(phi[x >= clamp][0]) - 1.0) <= 2e-6      # exact ends behind the clamp

@@ -4,7 +4,7 @@
 for round in 1 2; do
   for spec in "$@"; do
     name=${spec%%=*}; envs=${spec#*=}
-    env $envs DD_PROFILE_DUMP=$PWD/gpurun_out/ops_$name.csv timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_cli 2>gpurun_out/ab_$name.err | tail -1 > gpurun_out/ab_$name.json || exit 1
+    env $envs DD_PROFILE_DUMP=$PWD/gpurun_out/ops_$name.csv timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_cli --no_strength1 2>gpurun_out/ab_$name.err | tail -1 > gpurun_out/ab_$name.json || exit 1
     python - "$name" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/ab_%s.json" % sys.argv[1]).read())
