@@ -59,6 +59,10 @@ __device__ unsigned long long g_ws_trace[8 * 16 * 10];
 #endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifndef WS_VAR
+#define WS_VAR 1      // A/B switches of this file: 1 hand-built fragment addresses (374 -> 341 vector instructions per GEGLU tile and wave, 235 -> 182 VGPRs;
+                      // isolated 581 -> 577 us: kept for the registers), 2 / 4 s_setprio 1 for waves 4 .. 7 / 0 .. 3 (no gain: profiles/r06_ws_variants.txt)
+#endif
 #ifndef WS_ABL
 #define WS_ABL 0      // timing ablations (results wrong): 1 no DMA behind the first two tiles, 2 no epilogue arithmetic, 4 no MFMAs, 8 no fragment reads, 16 no stores, 32 no barrier
 #endif
@@ -135,17 +139,34 @@ __device__ __forceinline__ void ws_wave(const ConvGemmParams& p, unsigned char* 
   // The sched_barrier lets VALU / SALU / MFMA cross (so the previous epilogue still interleaves with the next MFMAs) but no LDS or
   // memory instruction: left to itself the scheduler sinks each ds_read to just in front of its MFMA and every K chunk pays the LDS latency.
   bf16x8 xf[WS_KC];
+#if WS_VAR & 1
+  // the swizzle term depends on the lane only (row & 7 == fr & 7 for every 16-row step): two lane bases (even / odd K chunk), everything
+  // else -- step, 64-channel block -- is an immediate offset of the ds_read (the compiler otherwise keeps ~12 address registers and
+  // spends two integer instructions per fragment read on them)
+  const unsigned xfe = (unsigned)(fr * 128 + ((fq ^ (fr & 7)) << 4)), xfo = (unsigned)(fr * 128 + (((4 + fq) ^ (fr & 7)) << 4));
+#endif
   auto load_xf = [&](int slot, int a) {
     const int row = a * 16 + fr;
+#if WS_VAR & 1
+    typedef const __attribute__((address_space(3))) unsigned char* lds_cp;
+    unsigned be = lds0 + (unsigned)slot * WS_TILE_B + xfe, bo = lds0 + (unsigned)slot * WS_TILE_B + xfo;
+    asm volatile("" : "+v"(be), "+v"(bo));              // opaque: no strength reduction into a register per (step, parity)
+    const lds_cp Ae = (lds_cp)(unsigned long long)be, Ao = (lds_cp)(unsigned long long)bo;
+#pragma unroll
+    for (int kc = 0; kc < WS_KC; ++kc) xf[kc] = *(const __attribute__((address_space(3))) bf16x8*)(((kc & 1) ? Ao : Ae) + a * 2048 + (kc >> 1) * 8192);
+#else
     const unsigned char* At = smem + slot * WS_TILE_B + row * 128;
 #pragma unroll
     for (int kc = 0; kc < WS_KC; ++kc) {
       if (WS_ABL & 8) { if (slot == 0 && a == 0) xf[kc] = *(const bf16x8*)(At + kc * 16); continue; }
       xf[kc] = *(const bf16x8*)(At + (kc >> 1) * 8192 + ((((kc & 1) * 4 + fq) ^ (row & 7)) << 4));
     }
+#endif
     __builtin_amdgcn_sched_barrier(0x000F);
   };
   load_xf(0, 0);
+  if ((WS_VAR & 2) && HS) __builtin_amdgcn_s_setprio(1);      // the younger half loses every arbitration otherwise (MI355X guide, "Two waves per SIMD" item 4)
+  if ((WS_VAR & 4) && !HS) __builtin_amdgcn_s_setprio(1);
   for (int it = 0; it < count; ++it, tile += tstep) {
     const int slot = it % WS_SLOTS;
     const int m0 = tile * WS_RT;
