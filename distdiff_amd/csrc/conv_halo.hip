@@ -405,6 +405,169 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
 }
 
+// PERSISTENT form of the halo kernel for the tile shapes whose K loop is short (the decoder's levels: Cin = 128 / 256 / 512, i.e. 18 / 36 /
+// 72 K-steps per 512 x 128 tile).  There a tile's prologue (100 KB of halo + the first weight stage: DMA issue, flight and drain with
+// nothing beside them) and its epilogue (128 KB of stores + the GroupNorm partials) are a quarter of the tile, and with one workgroup per
+// CU (LDS) nothing overlaps them.  One workgroup per CU walks its tiles: behind the last K-step of a tile the halo buffer and the idle
+// weight stage are free, so the NEXT tile's first halo chunk, first weight stage and bias row are requested BEFORE this tile's epilogue
+// and land while it stores.  Same tile -> XCD map as the one-tile kernel (an XCD's workgroups share a contiguous tile range, n-tiles
+// fastest), same K loop, same epilogue; no CF_GNFOLD, N % BN == 0.  Results are bitwise those of conv_halo_kernel (same order of
+// operations per tile).
+template <int TN, int WN>
+__global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParams p, HaloGeo geo) {
+  const int lw = geo.ltw, halo_px = geo.halo_px;
+  constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
+  constexpr int NPC = BN / 8, NWP = (NPC + 7) / 8, WB = BN * 128;
+  static_assert((NPC & 7) == 0, "whole weight pieces per wave");
+  constexpr unsigned OOB = 0xfffffff0u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const halo = smem + 2 * WB;
+  float* const bias_base = (float*)(halo + ((halo_px + 7) & ~7) * 128);      // two slots of BN floats (tile parity)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int grp = wave >> 2;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int Wd = 1 << lw, W2 = Wd + 2;
+  const int ntn = p.N / BN, tiles = (p.M / BM) * ntn, tpi = geo.tiles_x * geo.tiles_y;
+  // tiles of this workgroup: XCD x owns [xs, xs + xc); its gridDim.x / 8 workgroups take xs + idx, xs + idx + per, ...
+  const int per = gridDim.x >> 3;
+  int xs, xc;
+  {
+    const int q = tiles >> 3, r = tiles & 7, xcd = blockIdx.x & 7;
+    xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xc = q + (xcd < r ? 1 : 0);
+  }
+  int t = blockIdx.x >> 3;
+  if (t >= xc) return;
+  const int chunks = p.cin >> 6, KT = chunks * 9;
+  const int v_taps = lane < 9 ? p.taptab[lane] : 0;
+  const int prow = lane >> 3, jw = (lane & 7) ^ prow;
+  constexpr int TNP = TN & ~1;
+  unsigned woff[NWP];                                   // lane part of the weight offsets (n0 goes into the scalar offset)
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) {
+    const int R = (wave + 8 * i) * 8 + prow;
+    const int wv = R / (TN * 16), q = R - wv * (TN * 16), jn = q >> 4, f = q & 15;
+    const int ch = jn < TNP ? wv * (TN * 16) + (jn >> 1) * 32 + (f >> 2) * 8 + (jn & 1) * 4 + (f & 3) : R;
+    woff[i] = ((unsigned)ch * (unsigned)p.K + (unsigned)(jw * 8)) * 2u;
+  }
+  const float inv_w2 = 1.f / (float)W2;
+  struct Tile { int n0, img, y0, x0; };
+  auto tile_of = [&](int tt) {
+    const int tile = xs + tt;
+    Tile g;
+    g.n0 = (tile % ntn) * BN;
+    const int mt = tile / ntn;
+    g.img = mt / tpi;
+    const int tin = mt - g.img * tpi;
+    g.y0 = (tin / geo.tiles_x) * geo.th; g.x0 = (tin % geo.tiles_x) << lw;
+    return g;
+  };
+  // weight K-step kt of tile g into stage st
+  auto issue_w = [&](const Tile& g, int kt, int st, int i) {
+    hdma16(p.w, smem + st * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)g.n0 * (unsigned)p.K * 2u + (unsigned)kt * 128u);
+  };
+  auto issue_halo = [&](const Tile& g, int chunk) {     // waves 0 .. 3
+    const bf16_t* ximg = p.x + (size_t)g.img * p.H * p.W * p.x_ld;
+    const int npc = (halo_px + 7) >> 3;
+    for (int pc = wave; pc < npc; pc += 4) {
+      const int hp = pc * 8 + prow;
+      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+      const int iy = g.y0 - 1 + hy, ix = g.x0 - 1 + hx;
+      const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
+      const int j = (lane & 7) ^ (hx & 7);
+      const unsigned voff = ok ? ((unsigned)((iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+      hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
+    }
+  };
+  auto stage_first = [&](const Tile& g, int st, int slot) {   // everything a tile needs before its first K-step
+    if (grp == 0) issue_halo(g, 0);
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) issue_w(g, 0, st, i);
+    if (tid < BN) bias_base[slot * BN + tid] = (p.flags & CF_BIAS) ? p.bias[g.n0 + tid] : 0.f;
+  };
+
+  Tile g = tile_of(t);
+  int kg = 0;                                             // K-steps issued so far: K-step kt of the current tile lives in stage (kg + kt) & 1
+  stage_first(g, 0, 0);
+  bf16x8 wf[TN], xf[8];
+  for (int it = 0;; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // halo chunk 0, weight stage, bias slot of this tile are in LDS
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // the second group runs one barrier behind
+    f32x4 acc[8][TN];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kt = 0;
+    for (int c = 0; c < chunks; ++c) {
+      if (c > 0) {
+        if (grp == 0) {
+          issue_halo(g, c);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      for (int tp = 0; tp < 9; ++tp, ++kt) {
+        const int e = __builtin_amdgcn_readlane(v_taps, tp);
+        const int dy = ((e >> 6) & 63) - 32, dx = (e & 63) - 32;
+        const int tapoff = dy * W2 + dx;
+        const int st = (kg + kt) & 1;
+        const unsigned char* Bb = smem + st * WB;
+        const bool more = kt + 1 < KT;
+        const int xsw = (fr + 1 + dx) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) {
+            const int row = wc * (TN * 16) + jn * 16 + fr;
+            wf[jn] = *(const bf16x8*)(Bb + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const int r = wr * 128 + a * 16 + fr;
+            const int hp = r + 2 * (r >> lw) + Wd + 3 + tapoff;
+            xf[a] = *(const bf16x8*)(halo + hp * 128 + (((fq + 4 * ks) ^ xsw) << 4));
+          }
+          if (ks == 0 && more) {
+#pragma unroll
+            for (int q = 0; q < NWP; ++q) issue_w(g, kt + 1, st ^ 1, q);
+          }
+          if (ks == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[a][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jn], xf[a], acc[a][jn], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // balance the barrier count of the two groups: every LDS read of this tile has retired
+    kg += KT;
+    const int tn_ = t + per;
+    const bool have_next = tn_ < xc;
+    Tile gn = g;
+    if (have_next) {
+      gn = tile_of(tn_);
+      stage_first(gn, kg & 1, (it + 1) & 1);            // lands under the epilogue below
+    }
+    const int mimg = g.img * p.Ho * p.Wo, y0 = g.y0, x0 = g.x0;
+    auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };
+    const float* bias_s = bias_base + (it & 1) * BN;
+    pp_epilogue<TN>(p, acc, m_of, wr, wc, g.n0, bias_s, bias_s, 0, fr, fq);
+    if (!have_next) break;
+    g = gn; t = tn_;
+  }
+}
+
 #ifdef DD_TRACE
 // debug build only (tools/pp_trace.py): per tile (wait for the first K-step, K loop start, K loop end, end of the epilogue) in s_memrealtime ticks (10 ns)
 __device__ unsigned long long g_pp_trace[8192 * 6];
@@ -640,6 +803,19 @@ hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t strea
   return hipGetLastError();
 }
 
+template <int TN, int WN>
+hipError_t run_halo_persist(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
+  constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
+  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * BN * 4 + 512 + 64;
+  static int attr = 0;
+  if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_persist_kernel<TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
+  static const int cus = [] { int d = 0, n = 256; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 8 ? n & ~7 : 8; }();
+  const int tiles = (p.M / BM) * (p.N / BN);
+  const int grid = tiles >= cus ? cus : (tiles + 7) & ~7;
+  hipLaunchKernelGGL((conv_halo_persist_kernel<TN, WN>), dim3(grid), dim3(512), lds, stream, p, g);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // chunk split of the 8 x 8 level (M = 64 pixels x images: 64 tiles of 256 x 320 at 64 images -- a quarter of the chip): the smallest
@@ -748,6 +924,11 @@ hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream)
   HaloGeo g;
   if (!halo_geometry(p, tn == 2 || tn == 6 || tn == 1 ? 512 : 256, &g)) return hipErrorInvalidValue;
   if (tn == 1) return run_halo<1, 2>(p, g, stream);
+  // 512 x 128 tiles with a short K loop (the decoder's levels): the persistent form, next tile's first stage requested under the epilogue
+  static const int persist = getenv("DD_HALO_PERSIST") ? atoi(getenv("DD_HALO_PERSIST")) : 1;
+  if (tn == 2 && persist && g.ipt == 1 && !(p.flags & CF_GNFOLD) && p.N % 128 == 0 && (p.cin >> 6) <= persist * 8 &&
+      2 * 128 * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * 128 * 4 + 512 + 64 <= 163840)
+    return run_halo_persist<4, 2>(p, g, stream);
   if (g.ipt > 1) return (tn == 5 && p.ksplit > 1 && (p.cin >> 6) % p.ksplit == 0) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
   return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
 }

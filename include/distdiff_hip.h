@@ -46,7 +46,7 @@ enum dd_status { DD_OK = 0, DD_ERR_ARG = -1, DD_ERR_HIP = -2, DD_ERR_STATE = -3,
 /* Layout version of the structs and argument lists of this header and distdiff_hip_ops.h.  A caller sets dd_config.abi_version =
  * DD_ABI_VERSION (after zero-initialising the struct: every struct of this ABI must be zero-initialised, new fields are appended and
  * mean "off" at 0); dd_create refuses another value with DD_ERR_ARG, and dd_abi_version() tells what the loaded library was built
- * as.  6: dd_config gained unet_attn_fp8 + abi_version; 5 (unversioned): workspace_bytes in the dd_op_attention_gemm_* lists,
+ * as.  6: dd_config gained unet_attn_fp8 + abi_version, AttnParams gained no_shortk; 5 (unversioned): workspace_bytes in the dd_op_attention_gemm_* lists,
  * ConvGemmParams.wgroup_rows / wgroup_elems, AttnParams.pv_fp8. */
 #define DD_ABI_VERSION 6
 

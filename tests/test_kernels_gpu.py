@@ -74,6 +74,13 @@ CONV_CASES = [
     ("halo_w256_2x128_tiles", 1, 64, 256, 256, 256, 3, 1, 1, 0),  # images wider than 128: 2 x 128-pixel tiles
     ("halo_w512_up2", 1, 64, 256, 64, 256, 3, 1, 1, 1),           # logical 128 x 512
     ("halo_n128_512x128_tiles", 1, 128, 128, 256, 512, 3, 1, 1, 0),  # N = 128: 512-row tiles (4 x 128 pixels), waves 4 x 2
+    # the PERSISTENT 512 x 128 form (conv_halo_persist_kernel: decoder levels, <= 8 chunks): workgroups that walk 2 - 3 tiles with the next
+    # tile's halo / first weight stage requested under the epilogue; an odd number of K-steps per tile (1 and 3 chunks: the weight stage
+    # parity flips from tile to tile), two n-tiles per pixel tile, a ragged tile count (288 tiles on 256 workgroups), fused upsample
+    ("halo_persist_n128_cin64_3tiles_oddK", 6, 64, 128, 256, 256, 3, 1, 1, 0),
+    ("halo_persist_n256_cin192_2ntiles", 3, 192, 256, 256, 256, 3, 1, 1, 0),
+    ("halo_persist_ragged_288_tiles", 9, 128, 128, 128, 128, 3, 1, 1, 0),
+    ("halo_persist_up2_cin128", 4, 128, 128, 128, 128, 3, 1, 1, 1),
     # the 8 x 8 level (M = 64 pixels x images): the halo-resident kernel with four whole images per 256-pixel tile and a split over the
     # 64-channel chunks into fp32 partial sums + the reduce kernel (4-way at 64 images, 8-way at 32), forward and input-gradient
     ("halo_8x8_multi_image_split4", 64, 1280, 1280, 8, 8, 3, 1, 1, 0),

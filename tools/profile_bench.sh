@@ -7,11 +7,11 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli > $OUT/stats.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli --no_strength1 > $OUT/stats.json 2> $OUT/stats.err
 echo "stats done" > $OUT/progress
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli --no_profile > $OUT/fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli --no_strength1 --no_profile > $OUT/fetch.json 2> $OUT/fetch.err
 echo "fetch done" >> $OUT/progress
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli --no_profile > $OUT/write.json 2> $OUT/write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_cli --no_strength1 --no_profile > $OUT/write.json 2> $OUT/write.err
 echo "write done" >> $OUT/progress
 cd $ROOT
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
