@@ -42,7 +42,9 @@ __device__ __forceinline__ float hrow16_sum(float v) {
 // CF_LNFOLD (out = rstd[m] * (acc - mean[m] * c1[n]) + b'[n]: the LayerNorm in front of this linear is folded into its weights) and
 // CF_ROWSTATS ((sum, sum^2) of every output row over this wave's TN * 16 columns, for the LayerNorm that consumes the tensor).
 // stats_s: the (mean, rstd) rows of the tile in LDS (persistent GEMM: they arrive with the bias through the LDS-DMA ring), or null (global loads).
-template <int TN, class MOf>
+// LA: 16-row tiles whose residual rows / statistics are requested together (2: one exposed memory latency per 32 rows; 4: per 64 rows --
+// 16 more registers, which only the TN = 4 forms have: with TN = 5 it spilled)
+template <int TN, int LA = 2, class MOf>
 __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc)[8][TN], MOf m_of, int wr, int wc, int n0,
                                             const float* bias_s, const float* c1_s, int span, int fr, int fq, const float* stats_s = nullptr) {
   constexpr int TNP = TN & ~1;
@@ -58,16 +60,16 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[jn][r] = 0.f; s2[jn][r] = 0.f; }
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-    // the residual rows / LayerNorm statistics of two 16-row tiles are requested before their first use: one exposed memory latency per
-    // 32 rows instead of one per tile pair (the accumulators and the GroupNorm sums leave ~50 registers free here)
-    uint4 rvp[2][TN / 2];
-    uint2 rvo[2];
-    float2 lst[2];
-    int mrow[2];
+    for (int hb = 0; hb < 4 / LA; ++hb) {
+    // the residual rows / LayerNorm statistics of LA 16-row tiles are requested before their first use: one exposed memory latency per
+    // 32 (64) rows instead of one per tile pair (the accumulators and the GroupNorm sums leave ~50 registers free here)
+    uint4 rvp[LA][TN / 2];
+    uint2 rvo[LA];
+    float2 lst[LA];
+    int mrow[LA];
 #pragma unroll
-    for (int a4 = 0; a4 < 2; ++a4) {
-      mrow[a4] = m_of(wr * 128 + (blk * 4 + hb * 2 + a4) * 16 + fr);
+    for (int a4 = 0; a4 < LA; ++a4) {
+      mrow[a4] = m_of(wr * 128 + (blk * 4 + hb * LA + a4) * 16 + fr);
       const bf16_t* rp = (const bf16_t*)p.res + (size_t)mrow[a4] * p.res_ld + wb;
       if (fl & CF_RES) {
 #pragma unroll
@@ -79,11 +81,11 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
         rvo[a4] = make_uint2(0, 0);
       }
       lst[a4] = !(fl & CF_LNFOLD) ? make_float2(0.f, 1.f)
-                : stats_s ? *(const float2*)(stats_s + (wr * 128 + (blk * 4 + hb * 2 + a4) * 16 + fr) * 2) : *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2);
+                : stats_s ? *(const float2*)(stats_s + (wr * 128 + (blk * 4 + hb * LA + a4) * 16 + fr) * 2) : *(const float2*)(p.ln_stats + (size_t)mrow[a4] * 2);
     }
 #pragma unroll
-    for (int a4 = 0; a4 < 2; ++a4) {
-      const int a = blk * 4 + hb * 2 + a4;
+    for (int a4 = 0; a4 < LA; ++a4) {
+      const int a = blk * 4 + hb * LA + a4;
       const int m = mrow[a4];
       bf16_t* yp = (bf16_t*)p.y + (size_t)m * p.y_ld;
       const float rs = lst[a4].y * p.alpha, nm = -lst[a4].y * lst[a4].x;      // CF_LNFOLD: rstd and -rstd * mean of this lane's row (1, 0 otherwise)
@@ -562,7 +564,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     const int mimg = g.img * p.Ho * p.Wo, y0 = g.y0, x0 = g.x0;
     auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };
     const float* bias_s = bias_base + (it & 1) * BN;
-    pp_epilogue<TN>(p, acc, m_of, wr, wc, g.n0, bias_s, bias_s, 0, fr, fq);
+#ifndef DD_PERSIST_LA
+#define DD_PERSIST_LA 4
+#endif
+    pp_epilogue<TN, DD_PERSIST_LA>(p, acc, m_of, wr, wc, g.n0, bias_s, bias_s, 0, fr, fq);
     if (!have_next) break;
     g = gn; t = tn_;
   }
