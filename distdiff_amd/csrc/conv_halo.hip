@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };
     const float* bias_s = bias_base + (it & 1) * BN;
 #ifndef DD_PERSIST_LA
-#define DD_PERSIST_LA 4
+#define DD_PERSIST_LA 2      // 4 measured 2-3 % SLOWER on every decoder shape (256 VGPRs + 10 spills; profiles/r06_decoder_persist.txt)
 #endif
     pp_epilogue<TN, DD_PERSIST_LA>(p, acc, m_of, wr, wc, g.n0, bias_s, bias_s, 0, fr, fq);
     if (!have_next) break;
