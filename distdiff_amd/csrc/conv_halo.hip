@@ -407,6 +407,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   }
 }
 
+#ifdef DD_TRACE
+// debug build only (tools/pp_trace.py, tools/halo_trace.py): per tile stamps in s_memrealtime ticks (10 ns)
+__device__ unsigned long long g_pp_trace[8192 * 6];
+#define HP_STAMP(t, i) do { if (threadIdx.x == 0 && (t) < 8192) g_pp_trace[(t) * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HP_STAMP(t, i) do { } while (0)
+#endif
 // PERSISTENT form of the halo kernel for the tile shapes whose K loop is short (the decoder's levels: Cin = 128 / 256 / 512, i.e. 18 / 36 /
 // 72 K-steps per 512 x 128 tile).  There a tile's prologue (100 KB of halo + the first weight stage: DMA issue, flight and drain with
 // nothing beside them) and its epilogue (128 KB of stores + the GroupNorm partials) are a quarter of the tile, and with one workgroup per
@@ -496,8 +503,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
   stage_first(g, 0, 0);
   bf16x8 wf[TN], xf[8];
   for (int it = 0;; ++it) {
+    HP_STAMP(xs + t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // halo chunk 0, weight stage, bias slot of this tile are in LDS
+    HP_STAMP(xs + t, 1);
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the second group runs one barrier behind
     f32x4 acc[8][TN];
 #pragma unroll
@@ -553,6 +562,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
       }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // balance the barrier count of the two groups: every LDS read of this tile has retired
+    HP_STAMP(xs + t, 2);
     kg += KT;
     const int tn_ = t + per;
     const bool have_next = tn_ < xc;
@@ -561,6 +571,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
       gn = tile_of(tn_);
       stage_first(gn, kg & 1, (it + 1) & 1);            // lands under the epilogue below
     }
+    HP_STAMP(xs + t, 3);
     const int mimg = g.img * p.Ho * p.Wo, y0 = g.y0, x0 = g.x0;
     auto m_of = [&](int r) { return mimg + (y0 + (r >> lw)) * p.Wo + x0 + (r & (Wd - 1)); };
     const float* bias_s = bias_base + (it & 1) * BN;
@@ -568,15 +579,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
 #define DD_PERSIST_LA 2      // 4 measured 2-3 % SLOWER on every decoder shape (256 VGPRs + 10 spills; profiles/r06_decoder_persist.txt)
 #endif
     pp_epilogue<TN, DD_PERSIST_LA>(p, acc, m_of, wr, wc, g.n0, bias_s, bias_s, 0, fr, fq);
+    HP_STAMP(xs + t, 4);
     if (!have_next) break;
     g = gn; t = tn_;
   }
 }
 
-#ifdef DD_TRACE
-// debug build only (tools/pp_trace.py): per tile (wait for the first K-step, K loop start, K loop end, end of the epilogue) in s_memrealtime ticks (10 ns)
-__device__ unsigned long long g_pp_trace[8192 * 6];
-#endif
+// (DD_TRACE: g_pp_trace above -- persistent GEMM: wait for the first K-step, K loop start, K loop end, end of the epilogue)
 // GEGLU epilogue of the persistent ping-pong GEMM (TN = 4: a wave owns two packed (16 hidden | 16 gate) groups).  The weight rows are
 // assigned to MFMA rows so that a lane holds, per 16-row tile, the hidden AND gate pre-activations of 8 consecutive output columns
 // (fq * 8 .. + 7 of the wave's 32): 16-byte stores of the product and of both halves of the CF_GEGLU_RAW stash.  bias / c1 in packed order.
@@ -789,7 +798,11 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
     return true;
   }
   if (Wo < 16 || (Wo & (Wo - 1))) return false;
-  const int tw = Wo < 128 ? Wo : 128, th = bm / tw;
+  // wide images: 512-pixel tiles are 8 rows x 64 pixels (halo 10 x 66 = 660 pixels) rather than 4 x 128 (6 x 130 = 780): the halo refill
+  // at every 64-channel chunk boundary is the largest exposed cost of the decoder's short K loops (tools/halo_trace.py: ~5 us of a
+  // 14.6 us chunk), and it scales with the halo's bytes.  tw >= 64 keeps a CF_STATS block (64 consecutive output pixels) inside one row.
+  static const int tw512 = getenv("DD_HALO_TW512") ? atoi(getenv("DD_HALO_TW512")) : 64;
+  const int tw = Wo < 128 ? Wo : (bm == 512 ? tw512 : 128), th = bm / tw;
   if (Ho % th) return false;
   int l = 0;
   while ((1 << l) < tw) ++l;
