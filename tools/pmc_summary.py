@@ -13,7 +13,7 @@ from collections import defaultdict
 
 FAMILIES = (("conv_gemm_big_kernel", "conv_gemm_big_kernel"), ("conv_gemm_kernel", "conv_gemm_kernel"),
             ("attn_fwd_kernel", "attn_fwd"), ("attn_bwd", "attn_bwd"), ("gn_", "gn_"),
-            ("ln_", "ln_"), ("conv_halo_kernel", "conv_halo_kernel"), ("gemm_pp_kernel", "gemm_pp"), ("gemm_ws_kernel", "gemm_ws"), ("splitk", "splitk"))
+            ("ln_", "ln_"), ("conv_halo_kernel", "conv_halo_"), ("gemm_pp_kernel", "gemm_pp"), ("gemm_ws_kernel", "gemm_ws"), ("splitk", "splitk"))
 
 
 def fold(path, counter):
