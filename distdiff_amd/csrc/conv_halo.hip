@@ -160,7 +160,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 // Tile geometry (host: halo_geometry): a tile is th x tw OUTPUT pixels of one image (th * tw = 256, tw = min(Wo, 128) a power of two),
 // i.e. 256 / Wo whole image rows for Wo <= 128 and a 2 x 128 block for wider images; its halo is (th + 2) x (tw + 2) LOGICAL input
 // pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
-struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y, ipt; };   // ipt: images per tile (4 at 8 x 8: a tile is 4 whole images, each with its own 10 x 10 halo block)
+struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y, ipt, stagger; };   // stagger (persistent form): start delay per phase, in 10 ns ticks   // ipt: images per tile (4 at 8 x 8: a tile is 4 whole images, each with its own 10 x 10 halo block)
 
 // WN = 4: 256 x (64 TN) tiles, waves 2 (M) x 4 (N); WN = 2: 512 x (32 TN) tiles, waves 4 (M) x 2 (N) -- the narrow outputs of the decoder's
 // last level (N = 128).  Either way a wave owns 128 rows x TN * 16 columns and waves w, w + 4 (one SIMD) sit in different row groups.
@@ -450,6 +450,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
   }
   int t = blockIdx.x >> 3;
   if (t >= xc) return;
+  if (geo.stagger > 0) {
+    // de-phase the workgroups: launched together and walking tiles of identical cost they would refill their halos in the same
+    // microsecond, chip-wide, at the HBM rate (~11 B/clk per CU) instead of a CU's own (MI355X guide, "prologue HBM burst").  16 phases
+    // over the workgroups of an XCD; every wave of the workgroup waits the same time
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((blockIdx.x >> 3) & 15) * (unsigned)geo.stagger;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(4);
+  }
   const int chunks = p.cin >> 6, KT = chunks * 9;
   const int v_taps = lane < 9 ? p.taptab[lane] : 0;
   const int prow = lane >> 3, jw = (lane & 7) ^ prow;
@@ -794,7 +801,7 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   g->ipt = 1;
   if (Wo == 8 && Ho == 8 && bm == 256 && p.B % 4 == 0 && !p.shift) {
     // 8 x 8 level: a 256-pixel tile is four whole images, each with its own 10 x 10 halo block
-    g->ltw = 3; g->th = 8; g->halo_px = 4 * 100; g->tiles_x = 1; g->tiles_y = 1; g->ipt = 4;
+    g->ltw = 3; g->th = 8; g->halo_px = 4 * 100; g->tiles_x = 1; g->tiles_y = 1; g->ipt = 4; g->stagger = 0;
     return true;
   }
   if (Wo < 16 || (Wo & (Wo - 1))) return false;
@@ -807,6 +814,8 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   int l = 0;
   while ((1 << l) < tw) ++l;
   g->ltw = l; g->th = th; g->halo_px = (th + 2) * (tw + 2); g->tiles_x = Wo / tw; g->tiles_y = Ho / th;
+  static const int stagger = getenv("DD_HALO_STAGGER") ? atoi(getenv("DD_HALO_STAGGER")) : 0;
+  g->stagger = stagger;
   return true;
 }
 
