@@ -524,7 +524,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     for (int c = 0; c < chunks; ++c) {
       if (c > 0) {
         if (grp == 0) {
-          issue_halo(g, c);
+#ifndef DD_PERSIST_ABL
+#define DD_PERSIST_ABL 0      // timing ablations (results wrong): 1 no refill at the chunk boundary; 2 the refill re-reads chunk 0 (cache-hot lines, same issue work)
+#endif
+          if (DD_PERSIST_ABL != 1) issue_halo(g, DD_PERSIST_ABL == 2 ? 0 : c);
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
