@@ -160,7 +160,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 // Tile geometry (host: halo_geometry): a tile is th x tw OUTPUT pixels of one image (th * tw = 256, tw = min(Wo, 128) a power of two),
 // i.e. 256 / Wo whole image rows for Wo <= 128 and a 2 x 128 block for wider images; its halo is (th + 2) x (tw + 2) LOGICAL input
 // pixels (the fused nearest-2x upsample of the decoder's / UNet's upsamplers reads stored pixel (iy >> shift, ix >> shift)).
-struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y, ipt, stagger; };   // stagger (persistent form): start delay per phase, in 10 ns ticks   // ipt: images per tile (4 at 8 x 8: a tile is 4 whole images, each with its own 10 x 10 halo block)
+struct HaloGeo { int ltw, th, halo_px, tiles_x, tiles_y, ipt, stagger, tab; };   // tab: the one-tile kernel uses the LDS halo address table   // stagger (persistent form): start delay per phase, in 10 ns ticks   // ipt: images per tile (4 at 8 x 8: a tile is 4 whole images, each with its own 10 x 10 halo block)
 
 // WN = 4: 256 x (64 TN) tiles, waves 2 (M) x 4 (N); WN = 2: 512 x (32 TN) tiles, waves 4 (M) x 2 (N) -- the narrow outputs of the decoder's
 // last level (N = 128).  Either way a wave owns 128 rows x TN * 16 columns and waves w, w + 4 (one SIMD) sit in different row groups.
@@ -231,8 +231,42 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
   const float inv_w2 = 1.f / (float)W2;
   const bf16_t* ximg = p.x + (size_t)img * p.H * p.W * p.x_ld;     // per-image base: 32-bit byte offsets only span one image
+  // Halo address table (one-image tiles with geo.tab set; see conv_halo_persist_kernel): built once per workgroup behind the bias / coef
+  // block, entry (piece, lane) = halo row | halo column | byte offset from the halo's first stored pixel / 16
+  unsigned* const htab = (unsigned*)(coef_s + 128);
+  const bool use_tab = !MI && geo.tab != 0;
+  const int oy_ = p.shift ? (y0 >> 1) - 1 : y0 - 1, ox_ = p.shift ? (x0 >> 1) - 1 : x0 - 1;
+  const bf16_t* const xo = ximg + ((long long)oy_ * p.W + ox_) * p.x_ld;
+  const unsigned ylo = (unsigned)max(0, 1 - y0), yn = (unsigned)min(geo.th + 2, p.Ho - y0 + 1) - ylo;
+  const unsigned xlo = (unsigned)max(0, 1 - x0), xn = (unsigned)min(Wd + 2, p.Wo - x0 + 1) - xlo;
+  auto build_tab = [&]() {
+    const int npc = (halo_px + 7) >> 3;
+    for (int pc = wave; pc < npc; pc += 8) {
+      const int hp = pc * 8 + prow;
+      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+      const int sy = p.shift ? (hy + 1) >> 1 : hy, sx = p.shift ? (hx + 1) >> 1 : hx;
+      const int j = (lane & 7) ^ (hx & 7);
+      const unsigned rel = ((unsigned)(sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
+      htab[pc * 64 + lane] = hp < halo_px ? ((unsigned)hy << 27) | ((unsigned)hx << 19) | (rel >> 4) : 0xf8000000u;
+    }
+  };
   auto issue_halo = [&](int chunk) {
     const int npc = (halo_px + 7) >> 3;
+    if (use_tab) {
+      const unsigned soff = (unsigned)chunk * 128u;
+      for (int pc = wave; pc < npc; pc += 16) {         // four pieces per round: table reads first, then the requests back to back
+        unsigned e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = pc + 4 * u < npc ? htab[(pc + 4 * u) * 64 + lane] : 0xf8000000u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (pc + 4 * u >= npc) break;
+          const bool ok = ((e[u] >> 27) - ylo) < yn && (((e[u] >> 19) & 255u) - xlo) < xn;
+          hdma16(xo, halo + (pc + 4 * u) * 1024, ok ? (e[u] & 0x7ffffu) << 4 : OOB, soff);
+        }
+      }
+      return;
+    }
     for (int pc = wave; pc < npc; pc += 4) {
       const int hp = pc * 8 + prow;
       const int hi = MI ? (int)(((float)hp + 0.5f) * (1.f / (float)(himg > 0 ? himg : 1))) : 0;    // image of the tile
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 
   // ---- prologue
   if (gnf) load_coef(c_begin);
+  if (use_tab) { build_tab(); __syncthreads(); }
   if (grp == 0) issue_halo(c_begin);
 #pragma unroll
   for (int i = 0; i < NWP; ++i) issue_w(0, i);
@@ -470,6 +505,21 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     woff[i] = ((unsigned)ch * (unsigned)p.K + (unsigned)(jw * 8)) * 2u;
   }
   const float inv_w2 = 1.f / (float)W2;
+  // ---- halo address table (LDS, built once per workgroup): the LDS-DMA requests of a halo refill were bound by their ADDRESS ARITHMETIC
+  // (~35 instructions and two divergent branches per 1 KB piece: ~210 cycles a piece, 2.5 us per refill with cache-hot data as with cold,
+  // profiles/r06_decoder_persist.txt), and everything in it but the tile's origin is the same for every tile and chunk.  Entry (piece,
+  // lane) = halo row (5 bits) | halo column (8 bits) | byte offset from the halo's first pixel / 16 (19 bits, swizzle included); per
+  // tile only the origin pointer and the range of rows / columns that lie inside the image change (scalars).
+  unsigned* const htab = (unsigned*)(bias_base + 2 * BN);
+  const int npc = (halo_px + 7) >> 3;
+  for (int pc = wave; pc < npc; pc += 8) {
+    const int hp = pc * 8 + prow;
+    const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
+    const int sy = p.shift ? (hy + 1) >> 1 : hy, sx = p.shift ? (hx + 1) >> 1 : hx;     // stored pixel relative to the halo's first one
+    const int j = (lane & 7) ^ (hx & 7);
+    const unsigned rel = ((unsigned)(sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
+    htab[pc * 64 + lane] = hp < halo_px ? ((unsigned)hy << 27) | ((unsigned)hx << 19) | (rel >> 4) : 0xf8000000u;    // row 31: never inside
+  }
   struct Tile { int n0, img, y0, x0; };
   auto tile_of = [&](int tt) {
     const int tile = xs + tt;
@@ -486,16 +536,23 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     hdma16(p.w, smem + st * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)g.n0 * (unsigned)p.K * 2u + (unsigned)kt * 128u);
   };
   auto issue_halo = [&](const Tile& g, int chunk) {     // waves 0 .. 3
-    const bf16_t* ximg = p.x + (size_t)g.img * p.H * p.W * p.x_ld;
-    const int npc = (halo_px + 7) >> 3;
-    for (int pc = wave; pc < npc; pc += 4) {
-      const int hp = pc * 8 + prow;
-      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
-      const int iy = g.y0 - 1 + hy, ix = g.x0 - 1 + hx;
-      const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
-      const int j = (lane & 7) ^ (hx & 7);
-      const unsigned voff = ok ? ((unsigned)((iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
-      hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
+    // first stored pixel of the halo (logical (y0 - 1, x0 - 1); may lie in front of the image: those lanes are masked below)
+    const int oy = p.shift ? (g.y0 >> 1) - 1 : g.y0 - 1, ox = p.shift ? (g.x0 >> 1) - 1 : g.x0 - 1;
+    const bf16_t* xo = p.x + ((long long)g.img * p.H * p.W + (long long)oy * p.W + ox) * p.x_ld;
+    // halo rows / columns inside the image: logical pixel y0 - 1 + hy in [0, Ho)
+    const unsigned ylo = (unsigned)max(0, 1 - g.y0), yn = (unsigned)min(geo.th + 2, p.Ho - g.y0 + 1) - ylo;
+    const unsigned xlo = (unsigned)max(0, 1 - g.x0), xn = (unsigned)min(Wd + 2, p.Wo - g.x0 + 1) - xlo;
+    const unsigned soff = (unsigned)chunk * 128u;
+    for (int pc = wave; pc < npc; pc += 16) {           // four pieces per round: table reads first, then the requests back to back
+      unsigned e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e[u] = pc + 4 * u < npc ? htab[(pc + 4 * u) * 64 + lane] : 0xf8000000u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (pc + 4 * u >= npc) break;
+        const bool ok = ((e[u] >> 27) - ylo) < yn && (((e[u] >> 19) & 255u) - xlo) < xn;
+        hdma16(xo, halo + (pc + 4 * u) * 1024, ok ? (e[u] & 0x7ffffu) << 4 : OOB, soff);
+      }
     }
   };
   auto stage_first = [&](const Tile& g, int st, int slot) {   // everything a tile needs before its first K-step
@@ -507,6 +564,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
 
   Tile g = tile_of(t);
   int kg = 0;                                             // K-steps issued so far: K-step kt of the current tile lives in stage (kg + kt) & 1
+  __syncthreads();                                      // the address table is complete
   stage_first(g, 0, 0);
   bf16x8 wf[TN], xf[8];
   for (int it = 0;; ++it) {
@@ -804,7 +862,7 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   g->ipt = 1;
   if (Wo == 8 && Ho == 8 && bm == 256 && p.B % 4 == 0 && !p.shift) {
     // 8 x 8 level: a 256-pixel tile is four whole images, each with its own 10 x 10 halo block
-    g->ltw = 3; g->th = 8; g->halo_px = 4 * 100; g->tiles_x = 1; g->tiles_y = 1; g->ipt = 4; g->stagger = 0;
+    g->ltw = 3; g->th = 8; g->halo_px = 4 * 100; g->tiles_x = 1; g->tiles_y = 1; g->ipt = 4; g->stagger = 0; g->tab = 0;
     return true;
   }
   if (Wo < 16 || (Wo & (Wo - 1))) return false;
@@ -818,25 +876,32 @@ bool halo_geometry(const ConvGemmParams& p, int bm, HaloGeo* g) {
   while ((1 << l) < tw) ++l;
   g->ltw = l; g->th = th; g->halo_px = (th + 2) * (tw + 2); g->tiles_x = Wo / tw; g->tiles_y = Ho / th;
   static const int stagger = getenv("DD_HALO_STAGGER") ? atoi(getenv("DD_HALO_STAGGER")) : 0;
-  g->stagger = stagger;
+  g->stagger = stagger; g->tab = 0;
   return true;
 }
 
 template <int TN, int WN, bool MI = false>
 hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
-  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
+  int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
+  // halo address table behind the bias / coef block when it fits and the packed fields hold (row < 31, column < 256, offsets < 8 MB)
+  static const int tab_on = getenv("DD_HALO_TAB") ? atoi(getenv("DD_HALO_TAB")) : 1;
+  HaloGeo gg = g;
+  const int tab_bytes = ((g.halo_px + 7) >> 3) * 256;
+  gg.tab = (!MI && tab_on && g.ipt == 1 && g.th + 2 < 31 && (1 << g.ltw) + 2 < 256 && (size_t)(g.th + 3) * p.W * p.x_ld * 2 < (8u << 20) &&
+            lds + tab_bytes <= 163840) ? 1 : 0;
+  if (gg.tab) lds += tab_bytes;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
   const int tiles = (p.M / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((conv_halo_kernel<TN, WN, MI>), dim3(tiles, MI ? p.ksplit : 1), dim3(512), lds, stream, p, g);
+  hipLaunchKernelGGL((conv_halo_kernel<TN, WN, MI>), dim3(tiles, MI ? p.ksplit : 1), dim3(512), lds, stream, p, gg);
   return hipGetLastError();
 }
 
 template <int TN, int WN>
 hipError_t run_halo_persist(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
-  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * BN * 4 + 512 + 64;
+  const int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * BN * 4 + ((g.halo_px + 7) >> 3) * 256 + 64;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_persist_kernel<TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
   static const int cus = [] { int d = 0, n = 256; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 8 ? n & ~7 : 8; }();
@@ -956,8 +1021,10 @@ hipError_t launch_conv_halo(const ConvGemmParams& p, int tn, hipStream_t stream)
   if (tn == 1) return run_halo<1, 2>(p, g, stream);
   // 512 x 128 tiles with a short K loop (the decoder's levels): the persistent form, next tile's first stage requested under the epilogue
   static const int persist = getenv("DD_HALO_PERSIST") ? atoi(getenv("DD_HALO_PERSIST")) : 1;
+  // (address table: halo row < 31, column < 256, byte offsets inside the halo's stored rows below 8 MB)
   if (tn == 2 && persist && g.ipt == 1 && !(p.flags & CF_GNFOLD) && p.N % 128 == 0 && (p.cin >> 6) <= persist * 8 &&
-      2 * 128 * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * 128 * 4 + 512 + 64 <= 163840)
+      g.th + 2 < 31 && (1 << g.ltw) + 2 < 256 && (size_t)(g.th + 3) * p.W * p.x_ld * 2 < (8u << 20) &&
+      2 * 128 * 128 + ((g.halo_px + 7) & ~7) * 128 + 2 * 128 * 4 + ((g.halo_px + 7) >> 3) * 256 + 64 <= 163840)
     return run_halo_persist<4, 2>(p, g, stream);
   if (g.ipt > 1) return (tn == 5 && p.ksplit > 1 && (p.cin >> 6) % p.ksplit == 0) ? run_halo<5, 4, true>(p, g, stream) : hipErrorInvalidValue;
   return tn == 5 ? run_halo<5, 4>(p, g, stream) : tn == 4 ? run_halo<4, 4>(p, g, stream) : tn == 6 ? run_halo<5, 2>(p, g, stream) : run_halo<4, 2>(p, g, stream);
