@@ -231,53 +231,47 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
   // ---- halo staging (row half 0 only): pieces wave, wave + 4, ... of ceil(halo_px / 8); a lane's pixel hp = 8 * piece + (lane >> 3)
   const float inv_w2 = 1.f / (float)W2;
   const bf16_t* ximg = p.x + (size_t)img * p.H * p.W * p.x_ld;     // per-image base: 32-bit byte offsets only span one image
-  // Halo address table (one-image tiles with geo.tab set; see conv_halo_persist_kernel): built once per workgroup behind the bias / coef
-  // block, entry (piece, lane) = halo row | halo column | byte offset from the halo's first stored pixel / 16
+  // Halo address table (geo.tab; see 3.8.8 of DESIGN.md and conv_halo_persist_kernel): a workgroup of this kernel has ONE tile, so the byte
+  // offset of every (piece, lane) of its halo -- out-of-image pixels as the out-of-range offset that reads zeros -- is the same for every
+  // chunk.  All 8 waves compute their pieces once, in the prologue, store them behind the bias / coef block and request chunk c_begin with
+  // them; the refills at the chunk boundaries (row group 0) are a table read + a request per piece.
   unsigned* const htab = (unsigned*)(coef_s + 128);
-  const bool use_tab = !MI && geo.tab != 0;
-  const int oy_ = p.shift ? (y0 >> 1) - 1 : y0 - 1, ox_ = p.shift ? (x0 >> 1) - 1 : x0 - 1;
-  const bf16_t* const xo = ximg + ((long long)oy_ * p.W + ox_) * p.x_ld;
-  const unsigned ylo = (unsigned)max(0, 1 - y0), yn = (unsigned)min(geo.th + 2, p.Ho - y0 + 1) - ylo;
-  const unsigned xlo = (unsigned)max(0, 1 - x0), xn = (unsigned)min(Wd + 2, p.Wo - x0 + 1) - xlo;
-  auto build_tab = [&]() {
+  const bool use_tab = geo.tab != 0;
+  auto halo_voff = [&](int pc) {
+    const int hp = pc * 8 + prow;
+    const int hi = MI ? (int)(((float)hp + 0.5f) * (1.f / (float)(himg > 0 ? himg : 1))) : 0;    // image of the tile
+    const int hq = hp - hi * himg;
+    const int hy = (int)(((float)hq + 0.5f) * inv_w2), hx = hq - hy * W2;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;       // logical input pixel (= output pixel coordinates: stride 1, pad 1)
+    const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
+    const int j = (lane & 7) ^ (hx & 7);
+    return ok ? ((unsigned)(hi * p.H * p.W + (iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
+  };
+  auto first_halo = [&](int chunk) {                     // prologue, all 8 waves
     const int npc = (halo_px + 7) >> 3;
     for (int pc = wave; pc < npc; pc += 8) {
-      const int hp = pc * 8 + prow;
-      const int hy = (int)(((float)hp + 0.5f) * inv_w2), hx = hp - hy * W2;
-      const int sy = p.shift ? (hy + 1) >> 1 : hy, sx = p.shift ? (hx + 1) >> 1 : hx;
-      const int j = (lane & 7) ^ (hx & 7);
-      const unsigned rel = ((unsigned)(sy * p.W + sx) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u;
-      htab[pc * 64 + lane] = hp < halo_px ? ((unsigned)hy << 27) | ((unsigned)hx << 19) | (rel >> 4) : 0xf8000000u;
+      const unsigned voff = halo_voff(pc);
+      htab[pc * 64 + lane] = voff;
+      hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
     }
   };
-  auto issue_halo = [&](int chunk) {
+  auto issue_halo = [&](int chunk) {                     // row group 0 (waves 0 .. 3)
     const int npc = (halo_px + 7) >> 3;
+    const unsigned soff = (unsigned)chunk * 128u;
     if (use_tab) {
-      const unsigned soff = (unsigned)chunk * 128u;
       for (int pc = wave; pc < npc; pc += 16) {         // four pieces per round: table reads first, then the requests back to back
         unsigned e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = pc + 4 * u < npc ? htab[(pc + 4 * u) * 64 + lane] : 0xf8000000u;
+        for (int u = 0; u < 4; ++u) e[u] = pc + 4 * u < npc ? htab[(pc + 4 * u) * 64 + lane] : OOB;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (pc + 4 * u >= npc) break;
-          const bool ok = ((e[u] >> 27) - ylo) < yn && (((e[u] >> 19) & 255u) - xlo) < xn;
-          hdma16(xo, halo + (pc + 4 * u) * 1024, ok ? (e[u] & 0x7ffffu) << 4 : OOB, soff);
+          hdma16(ximg, halo + (pc + 4 * u) * 1024, e[u], soff);
         }
       }
       return;
     }
-    for (int pc = wave; pc < npc; pc += 4) {
-      const int hp = pc * 8 + prow;
-      const int hi = MI ? (int)(((float)hp + 0.5f) * (1.f / (float)(himg > 0 ? himg : 1))) : 0;    // image of the tile
-      const int hq = hp - hi * himg;
-      const int hy = (int)(((float)hq + 0.5f) * inv_w2), hx = hq - hy * W2;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;       // logical input pixel (= output pixel coordinates: stride 1, pad 1)
-      const bool ok = hp < halo_px && iy >= 0 && iy < p.Ho && ix >= 0 && ix < p.Wo;
-      const int j = (lane & 7) ^ (hx & 7);
-      const unsigned voff = ok ? ((unsigned)(hi * p.H * p.W + (iy >> p.shift) * p.W + (ix >> p.shift)) * (unsigned)p.x_ld + (unsigned)(j * 8)) * 2u : OOB;
-      hdma16(ximg, halo + pc * 1024, voff, (unsigned)chunk * 128u);
-    }
+    for (int pc = wave; pc < npc; pc += 4) hdma16(ximg, halo + pc * 1024, halo_voff(pc), soff);
   };
 
   // CF_GNFOLD: GroupNorm(+SiLU) applied to the staged halo chunk in place -- y = silu(x * a[c] + b[c]) on every pixel that lies inside
@@ -318,8 +312,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvGemmParams p, Hal
 
   // ---- prologue
   if (gnf) load_coef(c_begin);
-  if (use_tab) { build_tab(); __syncthreads(); }
-  if (grp == 0) issue_halo(c_begin);
+  if (use_tab) first_halo(c_begin);
+  else if (grp == 0) issue_halo(c_begin);
 #pragma unroll
   for (int i = 0; i < NWP; ++i) issue_w(0, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -884,12 +878,11 @@ template <int TN, int WN, bool MI = false>
 hipError_t run_halo(const ConvGemmParams& p, const HaloGeo& g, hipStream_t stream) {
   constexpr int BM = (8 / WN) * 128, BN = WN * TN * 16;
   int lds = 2 * BN * 128 + ((g.halo_px + 7) & ~7) * 128 + BN * 4 + 512 + 64;
-  // halo address table behind the bias / coef block when it fits and the packed fields hold (row < 31, column < 256, offsets < 8 MB)
+  // halo address table behind the bias / coef block when it fits
   static const int tab_on = getenv("DD_HALO_TAB") ? atoi(getenv("DD_HALO_TAB")) : 1;
   HaloGeo gg = g;
   const int tab_bytes = ((g.halo_px + 7) >> 3) * 256;
-  gg.tab = (!MI && tab_on && g.ipt == 1 && g.th + 2 < 31 && (1 << g.ltw) + 2 < 256 && (size_t)(g.th + 3) * p.W * p.x_ld * 2 < (8u << 20) &&
-            lds + tab_bytes <= 163840) ? 1 : 0;
+  gg.tab = (tab_on && lds + tab_bytes <= 163840) ? 1 : 0;
   if (gg.tab) lds += tab_bytes;
   static int attr = 0;
   if (attr < lds) { hipFuncSetAttribute((const void*)conv_halo_kernel<TN, WN, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = lds; }
