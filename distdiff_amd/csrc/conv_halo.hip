@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
   auto issue_w = [&](const Tile& g, int kt, int st, int i) {
     hdma16(p.w, smem + st * WB + (wave + 8 * i) * 1024, woff[i], (unsigned)g.n0 * (unsigned)p.K * 2u + (unsigned)kt * 128u);
   };
-  auto issue_halo = [&](const Tile& g, int chunk) {     // waves 0 .. 3
+  auto issue_halo = [&](const Tile& g, int chunk, int nw) {     // nw = 4: waves 0 .. 3 (refill inside the K loop); 8: all waves (between tiles)
     // first stored pixel of the halo (logical (y0 - 1, x0 - 1); may lie in front of the image: those lanes are masked below)
     const int oy = p.shift ? (g.y0 >> 1) - 1 : g.y0 - 1, ox = p.shift ? (g.x0 >> 1) - 1 : g.x0 - 1;
     const bf16_t* xo = p.x + ((long long)g.img * p.H * p.W + (long long)oy * p.W + ox) * p.x_ld;
@@ -537,20 +537,20 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
     const unsigned ylo = (unsigned)max(0, 1 - g.y0), yn = (unsigned)min(geo.th + 2, p.Ho - g.y0 + 1) - ylo;
     const unsigned xlo = (unsigned)max(0, 1 - g.x0), xn = (unsigned)min(Wd + 2, p.Wo - g.x0 + 1) - xlo;
     const unsigned soff = (unsigned)chunk * 128u;
-    for (int pc = wave; pc < npc; pc += 16) {           // four pieces per round: table reads first, then the requests back to back
+    for (int pc = wave; pc < npc; pc += 4 * nw) {       // four pieces per round: table reads first, then the requests back to back
       unsigned e[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) e[u] = pc + 4 * u < npc ? htab[(pc + 4 * u) * 64 + lane] : 0xf8000000u;
+      for (int u = 0; u < 4; ++u) e[u] = pc + nw * u < npc ? htab[(pc + nw * u) * 64 + lane] : 0xf8000000u;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (pc + 4 * u >= npc) break;
+        if (pc + nw * u >= npc) break;
         const bool ok = ((e[u] >> 27) - ylo) < yn && (((e[u] >> 19) & 255u) - xlo) < xn;
-        hdma16(xo, halo + (pc + 4 * u) * 1024, ok ? (e[u] & 0x7ffffu) << 4 : OOB, soff);
+        hdma16(xo, halo + (pc + nw * u) * 1024, ok ? (e[u] & 0x7ffffu) << 4 : OOB, soff);
       }
     }
   };
-  auto stage_first = [&](const Tile& g, int st, int slot) {   // everything a tile needs before its first K-step
-    if (grp == 0) issue_halo(g, 0);
+  auto stage_first = [&](const Tile& g, int st, int slot) {   // everything a tile needs before its first K-step (all waves are between tiles here)
+    issue_halo(g, 0, 8);
 #pragma unroll
     for (int i = 0; i < NWP; ++i) issue_w(g, 0, st, i);
     if (tid < BN) bias_base[slot * BN + tid] = (p.flags & CF_BIAS) ? p.bias[g.n0 + tid] : 0.f;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_persist_kernel(ConvGemmParam
 #ifndef DD_PERSIST_ABL
 #define DD_PERSIST_ABL 0      // timing ablations (results wrong): 1 no refill at the chunk boundary; 2 the refill re-reads chunk 0 (cache-hot lines, same issue work)
 #endif
-          if (DD_PERSIST_ABL != 1) issue_halo(g, DD_PERSIST_ABL == 2 ? 0 : c);
+          if (DD_PERSIST_ABL != 1) issue_halo(g, DD_PERSIST_ABL == 2 ? 0 : c, 4);
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
