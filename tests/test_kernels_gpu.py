@@ -6,6 +6,7 @@ round the result to bf16 once, so |err| <= ~2^-8 * |ref| + accumulation noise; c
 max|err| <= atol + rtol*max|ref| with the per-test values below.
 """
 import ctypes as C
+import os
 import math
 
 import pytest
@@ -984,3 +985,18 @@ def test_conv_emits_groupnorm_partials(ops, case):
     assert_close(ops.from_nhwc(got, B, H, W), want, what=name + " gn from partials")
     plain, stats2 = ops.groupnorm(yv, gamma.cuda(), beta.cuda(), B, H * W, G, eps, True)
     assert_close(stats, stats2, rtol=2e-3, atol=2e-3, what=name + " stats vs statistics pass")
+
+
+def test_halo_switch_fallbacks_stay_correct():
+    """The A/B switches of the halo kernels select code that the default configuration never runs (they are read once per process):
+    no address table (`DD_HALO_TAB=0`: per-piece address arithmetic, also what a geometry whose table does not fit in LDS gets), decoder
+    levels on the one-tile form (`DD_HALO_PERSIST=0`), 4 x 128-pixel tiles (`DD_HALO_TW512=128`, whose 780-pixel halo leaves no room for
+    the table in the 512 x 160 form).  The halo cases of this file again, in a child process with all three set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DD_HALO_TAB="0", DD_HALO_PERSIST="0", DD_HALO_TW512="128")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "test_conv_forward_and_dgrad and halo"], capture_output=True, text=True, timeout=900, env=env,
+                         cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-1000:]
